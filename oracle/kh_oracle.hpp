@@ -1,0 +1,509 @@
+// kh_oracle.hpp -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, never shipped, never on the product path).
+//
+// A plain, scalar C++11 restatement of the reference's hot path: the two open-addressing maps
+// fsc::hashmap_robinhood_doubling and fsc::hashmap_linearprobe_doubling plus the 64-bit hash
+// functors they are instantiated with.  Every function cites the reference file:line it follows
+// (paths relative to /root/reference/include/kmerhash/).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this code, and only
+// as the checker.  The product (kmerhash_amd/) never includes, links or calls anything in oracle/.
+//
+// PARITY PINNING STATUS
+//  * LP table  : PINNED. hashmap_linearprobe.hpp compiles from the reference tree as-is, so
+//                oracle/_ref/libref_lp.so (built by oracle/Makefile from the sources where they lie)
+//                is the real reference; tests/test_oracle_vs_ref.py and tests/golden/lp_*.npz compare
+//                this restatement with it result-for-result (size, capacity, info bytes, count, find,
+//                erase).
+//  * murmur3   : PINNED against smhasher MurmurHash3 (the third-party code hash_new.hpp:83 includes;
+//                an identical copy ships with scikit-learn 1.7.2 in this image) via tests/golden/
+//                murmur3_kat.npz, and against the two KATs SURVEY.md §8c records from the reference's
+//                own AVX implementation (key=1, seed=43).
+//  * RH table  : **PARITY UNPINNED** against a compiled reference: hashmap_robinhood.hpp:37 includes
+//                "io/incremental_mxx.hpp", a kmerind header that is absent here, so the RH header is
+//                unbuildable without writing a stand-in (which is not allowed).  The reference's own
+//                tests hold no golden vectors for it (they are differential against
+//                std::unordered_map).  What pins this restatement instead: (i) the same differential
+//                contract (tests/test_oracle.py), (ii) the behaviours SURVEY.md Appendix B recorded
+//                from the reference, (iii) occupancy equivalence with the *reference* LP table (a
+//                Robin Hood table and a linear-probing table over the same keys/hash/capacity occupy
+//                exactly the same slots), from which the canonical info array follows.
+//  * farmhash  : **PARITY UNPINNED** (google/farmhash source absent, no KAT in the reference tests).
+#ifndef KH_ORACLE_HPP_
+#define KH_ORACLE_HPP_
+
+#include <cstdint>
+#include <cstddef>
+#include <cstring>
+#include <vector>
+#include <utility>
+#include <stdexcept>
+#include <limits>
+
+namespace kh_oracle {
+
+// ---------------------------------------------------------------------------------------------
+// hashes
+// ---------------------------------------------------------------------------------------------
+enum HashId { HASH_IDENTITY = 0, HASH_MURMUR3_X86_128_LO64 = 1, HASH_MURMUR3_X64_128_H0 = 2, HASH_FARM64 = 3 };
+
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t rotr64(uint64_t x, int r) { return r == 0 ? x : (x >> r) | (x << (64 - r)); }
+
+static inline uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h;
+}
+static inline uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k;
+}
+
+// MurmurHash3_x86_128 (smhasher, public domain algorithm by A. Appleby); out[0..3] = h1..h4.
+// This is what fsc::hash::murmur3avx64 computes 8 keys at a time (murmurhash3_64_avx.hpp:1083-1169,
+// constants :1511-1521) and what fsc::hash::murmur_x86 calls (hash_new.hpp:218-233).
+static inline void murmur3_x86_128(const void* key, int len, uint32_t seed, uint32_t out[4]) {
+  const uint8_t* data = static_cast<const uint8_t*>(key);
+  const int nblocks = len / 16;
+  uint32_t h1 = seed, h2 = seed, h3 = seed, h4 = seed;
+  const uint32_t c1 = 0x239b961bu, c2 = 0xab0e9789u, c3 = 0x38b34ae5u, c4 = 0xa1e38b93u;
+  for (int i = 0; i < nblocks; ++i) {
+    uint32_t k1, k2, k3, k4;
+    memcpy(&k1, data + 16 * i + 0, 4); memcpy(&k2, data + 16 * i + 4, 4);
+    memcpy(&k3, data + 16 * i + 8, 4); memcpy(&k4, data + 16 * i + 12, 4);
+    k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2; h1 ^= k1;
+    h1 = rotl32(h1, 19); h1 += h2; h1 = h1 * 5 + 0x561ccd1bu;
+    k2 *= c2; k2 = rotl32(k2, 16); k2 *= c3; h2 ^= k2;
+    h2 = rotl32(h2, 17); h2 += h3; h2 = h2 * 5 + 0x0bcaa747u;
+    k3 *= c3; k3 = rotl32(k3, 17); k3 *= c4; h3 ^= k3;
+    h3 = rotl32(h3, 15); h3 += h4; h3 = h3 * 5 + 0x96cd1c35u;
+    k4 *= c4; k4 = rotl32(k4, 18); k4 *= c1; h4 ^= k4;
+    h4 = rotl32(h4, 13); h4 += h1; h4 = h4 * 5 + 0x32ac3b17u;
+  }
+  const uint8_t* tail = data + nblocks * 16;
+  uint32_t k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+  switch (len & 15) {
+    case 15: k4 ^= uint32_t(tail[14]) << 16;  // fallthrough
+    case 14: k4 ^= uint32_t(tail[13]) << 8;   // fallthrough
+    case 13: k4 ^= uint32_t(tail[12]) << 0;
+             k4 *= c4; k4 = rotl32(k4, 18); k4 *= c1; h4 ^= k4;  // fallthrough
+    case 12: k3 ^= uint32_t(tail[11]) << 24;  // fallthrough
+    case 11: k3 ^= uint32_t(tail[10]) << 16;  // fallthrough
+    case 10: k3 ^= uint32_t(tail[9]) << 8;    // fallthrough
+    case 9:  k3 ^= uint32_t(tail[8]) << 0;
+             k3 *= c3; k3 = rotl32(k3, 17); k3 *= c4; h3 ^= k3;  // fallthrough
+    case 8:  k2 ^= uint32_t(tail[7]) << 24;   // fallthrough
+    case 7:  k2 ^= uint32_t(tail[6]) << 16;   // fallthrough
+    case 6:  k2 ^= uint32_t(tail[5]) << 8;    // fallthrough
+    case 5:  k2 ^= uint32_t(tail[4]) << 0;
+             k2 *= c2; k2 = rotl32(k2, 16); k2 *= c3; h2 ^= k2;  // fallthrough
+    case 4:  k1 ^= uint32_t(tail[3]) << 24;   // fallthrough
+    case 3:  k1 ^= uint32_t(tail[2]) << 16;   // fallthrough
+    case 2:  k1 ^= uint32_t(tail[1]) << 8;    // fallthrough
+    case 1:  k1 ^= uint32_t(tail[0]) << 0;
+             k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2; h1 ^= k1;
+    default: break;
+  }
+  h1 ^= uint32_t(len); h2 ^= uint32_t(len); h3 ^= uint32_t(len); h4 ^= uint32_t(len);
+  h1 += h2; h1 += h3; h1 += h4; h2 += h1; h3 += h1; h4 += h1;
+  h1 = fmix32(h1); h2 = fmix32(h2); h3 = fmix32(h3); h4 = fmix32(h4);
+  h1 += h2; h1 += h3; h1 += h4; h2 += h1; h3 += h1; h4 += h1;
+  out[0] = h1; out[1] = h2; out[2] = h3; out[3] = h4;
+}
+
+// low 64 bits of MurmurHash3_x86_128 = what murmur3avx64<T>::operator() returns
+// (murmurhash3_64_avx.hpp:1568-1574 -> hash(...) :1584-1597; interleave (h1,h2) :1138-1158).
+static inline uint64_t murmur3_x86_128_lo64(const void* key, int len, uint32_t seed) {
+  uint32_t h[4];
+  murmur3_x86_128(key, len, seed, h);
+  return uint64_t(h[0]) | (uint64_t(h[1]) << 32);
+}
+
+// MurmurHash3_x64_128 (smhasher); fsc::hash::murmur<T> returns h[0] (hash_new.hpp:206-235).
+static inline void murmur3_x64_128(const void* key, int len, uint32_t seed, uint64_t out[2]) {
+  const uint8_t* data = static_cast<const uint8_t*>(key);
+  const int nblocks = len / 16;
+  uint64_t h1 = seed, h2 = seed;
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  for (int i = 0; i < nblocks; ++i) {
+    uint64_t k1, k2;
+    memcpy(&k1, data + 16 * i, 8); memcpy(&k2, data + 16 * i + 8, 8);
+    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  const uint8_t* tail = data + nblocks * 16;
+  uint64_t k1 = 0, k2 = 0;
+  switch (len & 15) {
+    case 15: k2 ^= uint64_t(tail[14]) << 48;  // fallthrough
+    case 14: k2 ^= uint64_t(tail[13]) << 40;  // fallthrough
+    case 13: k2 ^= uint64_t(tail[12]) << 32;  // fallthrough
+    case 12: k2 ^= uint64_t(tail[11]) << 24;  // fallthrough
+    case 11: k2 ^= uint64_t(tail[10]) << 16;  // fallthrough
+    case 10: k2 ^= uint64_t(tail[9]) << 8;    // fallthrough
+    case 9:  k2 ^= uint64_t(tail[8]) << 0;
+             k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;  // fallthrough
+    case 8:  k1 ^= uint64_t(tail[7]) << 56;   // fallthrough
+    case 7:  k1 ^= uint64_t(tail[6]) << 48;   // fallthrough
+    case 6:  k1 ^= uint64_t(tail[5]) << 40;   // fallthrough
+    case 5:  k1 ^= uint64_t(tail[4]) << 32;   // fallthrough
+    case 4:  k1 ^= uint64_t(tail[3]) << 24;   // fallthrough
+    case 3:  k1 ^= uint64_t(tail[2]) << 16;   // fallthrough
+    case 2:  k1 ^= uint64_t(tail[1]) << 8;    // fallthrough
+    case 1:  k1 ^= uint64_t(tail[0]) << 0;
+             k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    default: break;
+  }
+  h1 ^= uint64_t(len); h2 ^= uint64_t(len);
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2; h2 += h1;
+  out[0] = h1; out[1] = h2;
+}
+static inline uint64_t murmur3_x64_128_h0(const void* key, int len, uint32_t seed) {
+  uint64_t h[2];
+  murmur3_x64_128(key, len, seed, h);
+  return h[0];
+}
+
+// google/farmhash util::Hash64WithSeed restricted to 8 <= len <= 16 (the HashLen0to16 branch every
+// farmhash variant takes for such inputs), as published in farmhash.cc (farmhashna):
+//   Hash64WithSeed(s,len,seed) = Hash64WithSeeds(s,len,k2,seed) = HashLen16(Hash64(s,len) - k2, seed)
+// fsc::hash::farm<T> calls it with seed 43 (hash_new.hpp:309-328).  PARITY UNPINNED (see header).
+static inline uint64_t farm_hashlen16_mul(uint64_t u, uint64_t v, uint64_t mul) {
+  uint64_t a = (u ^ v) * mul; a ^= (a >> 47);
+  uint64_t b = (v ^ a) * mul; b ^= (b >> 47);
+  b *= mul;
+  return b;
+}
+static inline uint64_t farm64_with_seed_len8to16(const void* key, size_t len, uint64_t seed) {
+  const uint64_t k2 = 0x9ae16a3b2f90404fULL;
+  const uint8_t* s = static_cast<const uint8_t*>(key);
+  uint64_t f0, f1;
+  memcpy(&f0, s, 8); memcpy(&f1, s + len - 8, 8);
+  uint64_t mul = k2 + len * 2;
+  uint64_t a = f0 + k2;
+  uint64_t b = f1;
+  uint64_t c = rotr64(b, 37) * mul + a;
+  uint64_t d = (rotr64(a, 25) + b) * mul;
+  uint64_t h = farm_hashlen16_mul(c, d, mul);
+  return farm_hashlen16_mul(h - k2, seed, 0x9ddfea08eb382d69ULL);
+}
+
+// identity (hash_new.hpp:135-166): low 64 bits of the key.
+static inline uint64_t hash_u64(int id, uint64_t key, uint64_t seed) {
+  switch (id) {
+    case HASH_IDENTITY: return key;
+    case HASH_MURMUR3_X86_128_LO64: return murmur3_x86_128_lo64(&key, 8, uint32_t(seed));
+    case HASH_MURMUR3_X64_128_H0: return murmur3_x64_128_h0(&key, 8, uint32_t(seed));
+    case HASH_FARM64: return farm64_with_seed_len8to16(&key, 8, seed);
+    default: throw std::invalid_argument("unknown hash id");
+  }
+}
+
+// math_utils.hpp:64-69: 1 << (64 - lzcnt(x-1)).  x == 0 shifts by 64 (UB in C++); on x86 the shift
+// count is taken mod 64, so the reference returns 1 there; we define that value.
+static inline uint64_t next_power_of_2(uint64_t x) {
+  if (x <= 1) return 1;
+  return uint64_t(1) << (64 - __builtin_clzll(x - 1));
+}
+
+// hashmap_robinhood.hpp:261-270, hashmap_linearprobe.hpp:232-241: thresholds are computed in float.
+static inline size_t load_threshold(size_t buckets, float lf) {
+  return static_cast<size_t>(static_cast<float>(buckets) * lf);
+}
+
+typedef std::pair<uint64_t, uint32_t> value_type;
+
+// ---------------------------------------------------------------------------------------------
+// Robin Hood table  (hashmap_robinhood.hpp)
+// ---------------------------------------------------------------------------------------------
+class RobinHood {
+ public:
+  static const unsigned char EMPTY = 0x00;   // :142
+  static const unsigned char NORMAL = 0x80;  // :144
+
+  size_t lsize, buckets, mask, min_load, max_load;
+  float min_load_factor, max_load_factor;
+  int hash_id; uint64_t seed;
+  std::vector<value_type> container;
+  std::vector<unsigned char> info;
+  bool probe_overflow;  // set when a probe distance reaches 128 (reference: assert :556 / silent wrap)
+  // statistics (REPROBE_STAT equivalents, :205-211)
+  size_t reprobes, max_reprobes, moves, max_moves;
+
+  // ctor :218-233
+  RobinHood(size_t capacity, float min_lf, float max_lf, int hid, uint64_t sd)
+      : lsize(0), buckets(next_power_of_2(capacity)), mask(buckets - 1), hash_id(hid), seed(sd),
+        container(buckets), info(buckets, EMPTY), probe_overflow(false),
+        reprobes(0), max_reprobes(0), moves(0), max_moves(0) {
+    set_min_load_factor(min_lf);
+    set_max_load_factor(max_lf);
+  }
+  uint64_t hash(uint64_t k) const { return hash_u64(hash_id, k, seed); }
+  void set_min_load_factor(float f) { min_load_factor = f; min_load = load_threshold(buckets, f); }  // :261
+  void set_max_load_factor(float f) { max_load_factor = f; max_load = load_threshold(buckets, f); }  // :267
+  size_t size() const { return lsize; }
+  size_t capacity() const { return buckets; }
+  void clear() { lsize = 0; std::fill(info.begin(), info.end(), EMPTY); }  // :413-416
+
+  // :421-426 grow only
+  void reserve(size_t n) {
+    if (n > max_load) rehash(static_cast<size_t>(static_cast<float>(n) / max_load_factor));
+  }
+  // :432-464 + copy :472-509
+  void rehash(size_t b) {
+    size_t n = next_power_of_2(b);
+    if (n != buckets) {
+      buckets = n; mask = buckets - 1;
+      std::vector<value_type> tmp(buckets);
+      std::vector<unsigned char> tmp_info(buckets, EMPTY);
+      container.swap(tmp); info.swap(tmp_info);
+      lsize = 0;
+      min_load = load_threshold(buckets, min_load_factor);
+      max_load = load_threshold(buckets, max_load_factor);
+      for (size_t i = 0; i < tmp.size(); ++i)
+        if (tmp_info[i] >= NORMAL) insert(tmp[i].first, tmp[i].second);
+    }
+  }
+  // :522-624.  returns (position, inserted)
+  std::pair<size_t, bool> insert(uint64_t key, uint32_t val) {
+    unsigned char reprobe = NORMAL;
+    if (lsize >= max_load) rehash(buckets << 1);  // :530 (before probing; also on duplicates)
+    value_type vv(key, val);
+    size_t i = hash(key) & mask;
+    size_t insert_pos = std::numeric_limits<size_t>::max();
+    bool success = false;
+    size_t j = 0, probe_count = 0, move_count = 0;
+    for (; j < buckets; ++j) {
+      if (reprobe < NORMAL) probe_overflow = true;  // :556 assert
+      if (reprobe > info[i]) {
+        std::swap(info[i], reprobe);
+        if (insert_pos == std::numeric_limits<size_t>::max()) {
+          insert_pos = i; success = true; ++lsize; probe_count = j;
+        } else {
+          ++move_count;
+        }
+        if (reprobe == EMPTY) { container[i] = vv; break; }
+        std::swap(container[i], vv);
+      } else if (reprobe == info[i]) {
+        if (!success && container[i].first == vv.first) {  // :594
+          insert_pos = i; success = false; probe_count = j;
+          break;
+        }
+      }
+      ++reprobe;
+      i = (i + 1) & mask;
+    }
+    reprobes += probe_count; if (probe_count > max_reprobes) max_reprobes = probe_count;
+    moves += move_count; if (move_count > max_moves) max_moves = move_count;
+    return std::make_pair(insert_pos, success);
+  }
+  // :633-673 / :678-717 : loop + reserve(lsize)
+  size_t insert_batch(const uint64_t* keys, const uint32_t* vals, size_t n) {
+    size_t before = lsize, grown = 0;
+    for (size_t i = 0; i < n; ++i) { if (insert(keys[i], vals[i]).second) ++grown; }
+    (void)before;
+    reserve(lsize);
+    return grown;
+  }
+  // :1058-1095
+  size_t find_pos(uint64_t k) const {
+    unsigned char reprobe = NORMAL;
+    size_t i = hash(k) & mask;
+    size_t result = std::numeric_limits<size_t>::max();
+    for (size_t j = 0; j < buckets; ++j) {
+      if (reprobe > info[i]) break;
+      else if (reprobe == info[i]) {
+        if (k == container[i].first) { result = i; break; }
+      }
+      ++reprobe;
+      i = (i + 1) & mask;
+    }
+    return result;
+  }
+  size_t count(uint64_t k) const { return find_pos(k) < buckets ? 1 : 0; }  // :1102
+  // :1274-1284
+  size_t update(uint64_t k, uint32_t v) {
+    std::pair<size_t, bool> r = insert(k, v);
+    if (!r.second) container[r.first].second = v;
+    return r.first;
+  }
+  // :1294-1356
+  size_t erase_no_resize(uint64_t k) {
+    size_t found = find_pos(k);
+    if (found >= buckets) return 0;
+    --lsize;
+    size_t curr = found, next = (found + 1) & mask, move_count = 0;
+    unsigned char next_info = info[next];
+    if (next_info <= NORMAL) { info[curr] = EMPTY; return 1; }
+    size_t target = found;
+    for (size_t j = 0; j < buckets - 1; ++j) {
+      if (next_info <= NORMAL) break;
+      if (next_info <= info[curr]) {
+        info[curr] = next_info - 1;
+        container[target] = container[curr];
+        ++move_count;
+        target = curr;
+      }
+      curr = next; next = (next + 1) & mask; next_info = info[next];
+    }
+    info[curr] = EMPTY;
+    container[target] = container[curr];
+    ++move_count;
+    moves += move_count; if (move_count > max_moves) max_moves = move_count;
+    return 1;
+  }
+  // :1421-1428
+  size_t erase(uint64_t k) {
+    size_t r = erase_no_resize(k);
+    if (lsize < min_load) rehash(buckets >> 1);
+    return r;
+  }
+  // :1430-1440  (reserve() only grows, so a batch erase never shrinks)
+  size_t erase_batch(const uint64_t* keys, size_t n) {
+    size_t erased = 0;
+    for (size_t i = 0; i < n; ++i) erased += erase_no_resize(keys[i]);
+    if (lsize < min_load) reserve(lsize);
+    return erased;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// linear probing table  (hashmap_linearprobe.hpp)
+// ---------------------------------------------------------------------------------------------
+class LinearProbe {
+ public:
+  static const unsigned char EMPTY = 0x40;    // :114
+  static const unsigned char DELETED = 0x80;  // :115
+  static bool is_normal(unsigned char x) { return x < EMPTY; }  // :124
+
+  size_t lsize, buckets, min_load, max_load;
+  float min_load_factor, max_load_factor;
+  int hash_id; uint64_t seed;
+  std::vector<value_type> container;
+  std::vector<unsigned char> info;
+  size_t reprobes, max_reprobes;
+
+  // ctor :191-206 (defaults 0.2 / 0.6 are applied by the caller)
+  LinearProbe(size_t capacity, float min_lf, float max_lf, int hid, uint64_t sd)
+      : lsize(0), buckets(next_power_of_2(capacity)), hash_id(hid), seed(sd),
+        container(buckets), info(buckets, EMPTY), reprobes(0), max_reprobes(0) {
+    set_min_load_factor(min_lf);
+    set_max_load_factor(max_lf);
+  }
+  uint64_t hash(uint64_t k) const { return hash_u64(hash_id, k, seed); }
+  void set_min_load_factor(float f) { min_load_factor = f; min_load = load_threshold(buckets, f); }
+  void set_max_load_factor(float f) { max_load_factor = f; max_load = load_threshold(buckets, f); }
+  size_t size() const { return lsize; }
+  size_t capacity() const { return buckets; }
+  void clear() { lsize = 0; std::fill(info.begin(), info.end(), EMPTY); }  // :305-308
+  // :313-318
+  void reserve(size_t n) {
+    if (n > max_load) rehash(static_cast<size_t>(static_cast<float>(n) / max_load_factor));
+  }
+  // :324-349, copy :357-381, copy_one :389-422 (no duplicate check; drops tombstones; lsize kept)
+  void rehash(size_t b) {
+    size_t n = next_power_of_2(b);
+    if (n != buckets) {
+      buckets = n;
+      std::vector<value_type> tmp(buckets);
+      std::vector<unsigned char> tmp_info(buckets, EMPTY);
+      container.swap(tmp); info.swap(tmp_info);
+      min_load = load_threshold(buckets, min_load_factor);
+      max_load = load_threshold(buckets, max_load_factor);
+      for (size_t s = 0; s < tmp.size(); ++s) {
+        if (!is_normal(tmp_info[s])) continue;
+        if (buckets == 0) continue;
+        size_t pos = hash(tmp[s].first) % buckets;
+        size_t i = pos;
+        while (i < buckets && is_normal(info[i])) ++i;
+        if (i == buckets) {
+          i = 0;
+          while (i < pos && is_normal(info[i])) ++i;
+          if (i == pos) throw std::logic_error("ERROR: did not find any place to insert.  should not have happend");
+        }
+        container[i] = tmp[s];
+        info[i] = 0;
+      }
+    }
+  }
+  // :430-513
+  std::pair<size_t, bool> insert(uint64_t key, uint32_t val) {
+    if (buckets == 0) buckets = 1;
+    if (lsize >= max_load) rehash(buckets << 1);
+    size_t pos = hash(key) % buckets;
+    size_t i, insert_pos = buckets;
+    for (i = pos; i < buckets; ++i) {
+      if (info[i] == EMPTY) { insert_pos = i; break; }
+      if (info[i] == DELETED && insert_pos == buckets) insert_pos = i;
+      else if (is_normal(info[i]) && key == container[i].first) return std::make_pair(i, false);
+    }
+    if (i == buckets) {
+      for (i = 0; i < pos; ++i) {
+        if (info[i] == EMPTY) { insert_pos = i; break; }
+        if (info[i] == DELETED && insert_pos == buckets) insert_pos = i;
+        else if (is_normal(info[i]) && key == container[i].first) return std::make_pair(i, false);
+      }
+    }
+    if (insert_pos == buckets)
+      throw std::logic_error("ERROR: did not find a slot to insert into.  container must be full.  should not happen.");
+    container[insert_pos] = value_type(key, val);
+    info[insert_pos] = 0;
+    ++lsize;
+    return std::make_pair(insert_pos, true);
+  }
+  // :521-573
+  size_t insert_batch(const uint64_t* keys, const uint32_t* vals, size_t n) {
+    size_t count = 0;
+    for (size_t i = 0; i < n; ++i) if (insert(keys[i], vals[i]).second) ++count;
+    reserve(lsize);
+    return count;
+  }
+  // find :693-748 / count :580-634 : scan [pos,buckets) then [0,pos), stop at empty, skip deleted
+  size_t find_pos(uint64_t k) const {
+    if (buckets == 0) return std::numeric_limits<size_t>::max();
+    size_t pos = hash(k) % buckets, i;
+    for (i = pos; i < buckets; ++i) {
+      if (info[i] == EMPTY) break;
+      if (is_normal(info[i]) && k == container[i].first) return i;
+    }
+    if (i == buckets) {
+      for (i = 0; i < pos; ++i) {
+        if (info[i] == EMPTY) break;
+        if (is_normal(info[i]) && k == container[i].first) return i;
+      }
+    }
+    return std::numeric_limits<size_t>::max();
+  }
+  size_t count(uint64_t k) const { return find_pos(k) != std::numeric_limits<size_t>::max() ? 1 : 0; }
+  // :895-905
+  size_t update(uint64_t k, uint32_t v) {
+    std::pair<size_t, bool> r = insert(k, v);
+    if (!r.second) container[r.first].second = v;
+    return r.first;
+  }
+  // :911-978
+  size_t erase_no_resize(uint64_t k) {
+    size_t p = find_pos(k);
+    if (p == std::numeric_limits<size_t>::max()) return 0;
+    info[p] = DELETED;
+    --lsize;
+    return 1;
+  }
+  // :1032-1039
+  size_t erase(uint64_t k) {
+    size_t r = erase_no_resize(k);
+    if (lsize < min_load) rehash(buckets >> 1);
+    return r;
+  }
+  // :1042-1051 (can shrink)
+  size_t erase_batch(const uint64_t* keys, size_t n) {
+    size_t erased = 0;
+    for (size_t i = 0; i < n; ++i) erased += erase_no_resize(keys[i]);
+    if (lsize < min_load) rehash(static_cast<size_t>(static_cast<float>(lsize) / max_load_factor));
+    return erased;
+  }
+};
+
+}  // namespace kh_oracle
+#endif  // KH_ORACLE_HPP_
