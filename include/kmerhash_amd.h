@@ -1,0 +1,138 @@
+/* kmerhash_amd.h -- C-ABI of libkmerhash_amd.so: MI355X (gfx950) open-addressing k-mer hash tables.
+ *
+ * This is the drop-in boundary for ONE hot path of ParBLiSS/kmerhash: the batched
+ * insert / find / count / erase of
+ *     fsc::hashmap_robinhood_doubling   (reference include/kmerhash/hashmap_robinhood.hpp:124-126)
+ *     fsc::hashmap_linearprobe_doubling (reference include/kmerhash/hashmap_linearprobe.hpp:96-98)
+ * for 64-bit keys (2-bit packed k-mers, k <= 32) with 32-bit mapped values, and of the 64-bit hash
+ * functors they are instantiated with.  Plain pointers and sizes only; no C++/torch types cross it.
+ * The C++ template shim (include/kmerhash_amd/*.hpp) and the Python host layer (kmerhash_amd/) are
+ * thin callers of exactly these entry points; INTEGRATION.md shows the reference-side binding.
+ *
+ * Every function returns a kh_status; kh_last_error() gives the text of the last failure on a table.
+ * A table is single-writer (like the reference: not thread safe); read-only batches may not overlap
+ * a mutating batch.  All device work of a table is issued on its stream (kh_set_stream) and the
+ * functions that return scalar results (n_inserted, n_found, ...) synchronise that stream.
+ *
+ * Pointer arguments marked [h|d] live in host or device memory as told by the kh_mem argument;
+ * outputs live in the same space as the inputs of that call.  Device pointers must be valid on the
+ * table's device.
+ */
+#ifndef KMERHASH_AMD_H_
+#define KMERHASH_AMD_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kh_table kh_table;
+
+typedef enum {
+  KH_OK = 0,
+  KH_ERR_INVALID = 1,        /* bad argument / unsupported key or value width */
+  KH_ERR_NOMEM = 2,          /* device allocation failed */
+  KH_ERR_FULL = 3,           /* LP: no slot left -- mirrors std::logic_error, hashmap_linearprobe.hpp:408,503 */
+  KH_ERR_PROBE_OVERFLOW = 4, /* RH probe distance would reach 128: the reference asserts (hashmap_robinhood.hpp:556)
+                                or silently corrupts under -DNDEBUG; we refuse and leave the table unchanged */
+  KH_ERR_HIP = 5,            /* a HIP runtime call failed (no GPU, launch failure, ...) */
+  KH_ERR_UNSUPPORTED = 6
+} kh_status;
+
+typedef enum {
+  KH_KIND_ROBINHOOD = 0,     /* fsc::hashmap_robinhood_doubling  : info 0x00 empty, 0x80|dist occupied (:137-163) */
+  KH_KIND_LINEARPROBE = 1    /* fsc::hashmap_linearprobe_doubling: info 0x40 empty, 0x80 deleted, 0x00 normal (:109-139) */
+} kh_kind;
+
+typedef enum {
+  KH_HASH_IDENTITY = 0,             /* fsc::hash::identity<T>      hash_new.hpp:135-166 */
+  KH_HASH_MURMUR3_X86_128_LO64 = 1, /* fsc::hash::murmur3avx64<T>  murmurhash3_64_avx.hpp:1553-1651 (== murmur_x86, hash_new.hpp:218) */
+  KH_HASH_MURMUR3_X64_128_H0 = 2,   /* fsc::hash::murmur<T>        hash_new.hpp:206-235 */
+  KH_HASH_FARM64 = 3                /* fsc::hash::farm<T>          hash_new.hpp:309-328 (parity unpinned) */
+} kh_hash;
+
+typedef enum { KH_MEM_HOST = 0, KH_MEM_DEVICE = 1 } kh_mem;
+
+/* ---- lifetime: ctor (capacity=128, min_lf, max_lf)  hashmap_robinhood.hpp:218-233 / hashmap_linearprobe.hpp:191-206 */
+kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes /*8*/, uint32_t val_bytes /*4*/,
+                    kh_hash hash, uint64_t seed /*43*/, uint64_t capacity /*128*/,
+                    float min_load_factor, float max_load_factor, int device);
+kh_status kh_destroy(kh_table* t);
+kh_status kh_set_stream(kh_table* t, void* hip_stream /* hipStream_t; NULL = default stream */);
+const char* kh_last_error(const kh_table* t);
+
+/* ---- scalar state: size() :406 / capacity() :287 / load factors :261-285 / clear :413 / reserve :421 / rehash :432 */
+kh_status kh_size(const kh_table* t, uint64_t* out);
+kh_status kh_capacity(const kh_table* t, uint64_t* out);
+kh_status kh_get_load_thresholds(const kh_table* t, uint64_t* min_load, uint64_t* max_load);
+kh_status kh_set_min_load_factor(kh_table* t, float f);
+kh_status kh_set_max_load_factor(kh_table* t, float f);
+kh_status kh_get_load_factors(const kh_table* t, float* min_lf, float* max_lf, float* current);
+kh_status kh_clear(kh_table* t);
+kh_status kh_reserve(kh_table* t, uint64_t n);
+kh_status kh_rehash(kh_table* t, uint64_t buckets);
+
+/* ---- batch insert == insert(Iter,Iter) / insert(vector const&)  hashmap_robinhood.hpp:633-717,
+ *      hashmap_linearprobe.hpp:521-573.  First value wins; capacity follows the reference's doubling
+ *      rule exactly (one doubling per insert call made while size >= max_load, duplicates included). */
+kh_status kh_insert(kh_table* t, const void* keys /*[h|d] u64[n]*/, const void* vals /*[h|d] u32[n]*/,
+                    uint64_t n, kh_mem where, uint64_t* n_inserted);
+/* same, input as the reference's std::pair<uint64_t,uint32_t> array (16 B: key @0, value @8) */
+kh_status kh_insert_pairs(kh_table* t, const void* pairs16 /*[h|d]*/, uint64_t n, kh_mem where, uint64_t* n_inserted);
+/* update(k,v) applied in order to a batch: insert, or overwrite the existing value (last one wins)
+ *      hashmap_robinhood.hpp:1274-1284 / hashmap_linearprobe.hpp:895-905 */
+kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted);
+
+/* ---- count(Iter,Iter): 0/1 per query in query order  hashmap_robinhood.hpp:1111-1160 / hashmap_linearprobe.hpp:639-688
+ *      (the reference returns vector<size_t>; one byte per query here) */
+kh_status kh_count(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint8_t* out01 /*[h|d] u8[n]*/);
+
+/* ---- find: per-query form (value + found flag) and the reference's compacted form
+ *      find(Iter,Iter) -> vector<pair> of hits in query order  hashmap_robinhood.hpp:1194-1268 / hashmap_linearprobe.hpp:816-889 */
+kh_status kh_find(kh_table* t, const void* keys, uint64_t n, kh_mem where,
+                  uint32_t* out_vals /*[h|d] u32[n], untouched on miss*/, uint8_t* out_found /*[h|d] u8[n]*/, uint64_t* n_found);
+kh_status kh_find_compact(kh_table* t, const void* keys, uint64_t n, kh_mem where,
+                          uint64_t* out_keys /*[h|d] u64[n]*/, uint32_t* out_vals /*[h|d] u32[n]*/, uint64_t* n_found);
+kh_status kh_find_compact_pairs(kh_table* t, const void* keys, uint64_t n, kh_mem where,
+                                void* out_pairs16 /*[h|d] 16 B x n*/, uint64_t* n_found);
+
+/* ---- erase(Iter,Iter)  hashmap_robinhood.hpp:1430-1440 (never shrinks) / hashmap_linearprobe.hpp:1042-1051 (may shrink) */
+kh_status kh_erase(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint64_t* n_erased);
+/* erase(key) single-key form: also halves the table when size < min_load (:1421-1428 / :1032-1039) */
+kh_status kh_erase_one(kh_table* t, uint64_t key, uint64_t* n_erased);
+
+/* ---- iteration / parity exports (host buffers) */
+kh_status kh_to_vector(kh_table* t, uint64_t* keys_host, uint32_t* vals_host, uint64_t* n_out); /* to_vector() :388, slot order */
+kh_status kh_export_info(kh_table* t, uint8_t* out_host /* capacity bytes, reference encoding of the table's kind */);
+kh_status kh_export_slots(kh_table* t, uint64_t* keys_host, uint32_t* vals_host /* capacity entries; empty slots unspecified */);
+kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]); /* RH only: #slots per probe distance (REPROBE_STAT) */
+
+/* ---- batched hashing: Hash::operator()(Key const*, count, out)  murmurhash3_64_avx.hpp:1584-1597, hash_new.hpp:1035-1056 */
+kh_status kh_hash_batch(kh_hash hash, uint64_t seed, const void* keys, uint64_t n, kh_mem where,
+                        uint64_t* out /*[h|d]*/, int device, void* hip_stream);
+
+/* ---- key-space sharding for the multi-GPU layer: rank = hash(key, seed) & (p-1) (p power of two) or % p
+ *      (distributed_batched_robinhood_map.hpp:513-534,632-741 assign_count_permute).  Device buffers only.
+ *      out_* receive the pairs grouped by destination rank (rank 0 first, input order kept inside a rank);
+ *      counts_host[p] receives the per-rank element counts. */
+kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t nranks,
+                           const uint64_t* keys_dev, const uint32_t* vals_dev /* may be NULL */, uint64_t n,
+                           uint64_t* out_keys_dev, uint32_t* out_vals_dev /* may be NULL */,
+                           uint64_t* counts_host, int device, void* hip_stream);
+
+/* ---- measurement hooks: per-kernel HIP-event timing on the table's stream (bench.py roofline) */
+kh_status kh_profile_enable(kh_table* t, int on);
+kh_status kh_profile_reset(kh_table* t);
+/* total ms and launch count of kernels whose name starts with `prefix` since the last reset */
+kh_status kh_profile_query(kh_table* t, const char* prefix, double* total_ms, uint64_t* launches);
+/* writes up to `cap` bytes of "name launches total_ms\n" lines */
+kh_status kh_profile_dump(kh_table* t, char* buf, uint64_t cap);
+
+const char* kh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMERHASH_AMD_H_ */

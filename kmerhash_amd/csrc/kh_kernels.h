@@ -1,0 +1,818 @@
+// kh_kernels.h -- gfx950 device code of libkmerhash_amd (included once by kmerhash_amd.hip).
+//
+// Design: the table is SoA in HBM (keys u64[cap], vals u32[cap], info u8[cap]) and is
+// processed in CHUNKS of KH_L = 2^KH_LB consecutive home buckets.  A mutating batch never probes HBM
+// at random: the batch is radix-partitioned by (bit-reversed) chunk id with coalesced streaming
+// passes, each partition is de-duplicated first-value-wins inside LDS, and every chunk of the new
+// table is then laid out in its canonical Robin Hood order (elements sorted by home bucket, slot =
+// max(home, previous slot + 1)) by one workgroup that histograms the chunk's home buckets in LDS and
+// runs a max-plus scan over them; run-over between chunks is a (max,+) carry scanned across chunks.
+// Read-only batches (find/count) and erase marking probe the table directly, one query per lane.
+//
+// Wave64 everywhere; no MFMA (integer/indexing path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kh_hash.h"
+
+#define KH_LB 11                 // log2(chunk slots)
+#define KH_L (1u << KH_LB)       // chunk slots (home buckets per workgroup)
+#define KH_HS 4096u              // LDS de-dup set entries per workgroup (16 B each)
+#define KH_CHUNK_THREADS 512
+#define KH_PART_THREADS 512
+#define KH_PART_ITEMS 16
+#define KH_PART_TILE (KH_PART_THREADS * KH_PART_ITEMS)   // 8192 records per partition tile
+#define KH_NONE 0xFFFFFFFFFFFFFFFFull
+#define KH_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+enum { KHK_RH = 0, KHK_LP = 1 };
+enum { KH_FLAG_PROBE_OVERFLOW = 0, KH_FLAG_REGION_OVERFLOW = 1, KH_FLAG_COUNT_OVERFLOW = 2, KH_FLAG_INTERNAL = 3, KH_NFLAGS = 8 };
+
+// info-byte predicates of the two reference encodings
+template <int KIND> __device__ __forceinline__ bool kh_is_empty(uint32_t b) { return KIND == KHK_RH ? (b == 0x00u) : (b == 0x40u); }
+template <int KIND> __device__ __forceinline__ bool kh_is_occupied(uint32_t b) { return KIND == KHK_RH ? (b >= 0x80u) : (b < 0x40u); }
+
+struct KhSlots {
+  uint64_t* keys;
+  uint32_t* vals;
+  uint8_t* info;
+  uint64_t cap;   // power of two
+};
+
+// ---------------------------------------------------------------------------------------------
+// direct probing (find_pos): hashmap_robinhood.hpp:1058-1095 / hashmap_linearprobe.hpp:693-748
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ uint64_t kh_find_pos(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ info,
+                                                uint64_t mask, uint64_t home, uint64_t key) {
+  uint64_t i = home;
+  if (KIND == KHK_RH) {
+    // reprobe = 0x80 + distance; stop as soon as the resident entry is "richer" (or the slot is empty).
+    for (uint32_t reprobe = 0x80u; reprobe < 0x100u; ++reprobe) {
+      uint32_t b = info[i];
+      if (reprobe > b) return KH_NONE;
+      if (reprobe == b && keys[i] == key) return i;
+      i = (i + 1) & mask;
+    }
+    return KH_NONE;
+  } else {
+    // two-segment scan of the reference == circular scan; stop at empty, skip deleted
+    for (uint64_t step = 0; step <= mask; ++step) {
+      uint32_t b = info[i];
+      if (b == 0x40u) return KH_NONE;
+      if (b < 0x40u && keys[i] == key) return i;
+      i = (i + 1) & mask;
+    }
+    return KH_NONE;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched hashing  (Hash::operator()(Key const*, count, out))
+// ---------------------------------------------------------------------------------------------
+template <int HASH>
+__global__ void k_hash_batch(const uint64_t* __restrict__ keys, uint64_t n, uint64_t seed, uint64_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = kh_hash64<HASH>(keys[i], seed);
+}
+
+// ---------------------------------------------------------------------------------------------
+// count / find / erase-mark : one query per lane
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int HASH>
+__global__ void k_count(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, uint64_t seed, uint8_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t mask = T.cap - 1;
+  for (; i < n; i += stride) {
+    uint64_t key = q[i];
+    uint64_t pos = kh_find_pos<KIND>(T.keys, T.info, mask, kh_hash64<HASH>(key, seed) & mask, key);
+    out[i] = pos != KH_NONE ? 1 : 0;
+  }
+}
+
+template <int KIND, int HASH>
+__global__ void k_find(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, uint64_t seed,
+                       uint32_t* __restrict__ out_vals, uint8_t* __restrict__ out_found) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t mask = T.cap - 1;
+  for (; i < n; i += stride) {
+    uint64_t key = q[i];
+    uint64_t pos = kh_find_pos<KIND>(T.keys, T.info, mask, kh_hash64<HASH>(key, seed) & mask, key);
+    bool f = pos != KH_NONE;
+    out_found[i] = f ? 1 : 0;
+    if (f) out_vals[i] = T.vals[pos];
+  }
+}
+
+// RH: the table is not modified; hits are recorded in a bitmask (one bit per slot) and the table is
+//     then re-laid-out without them (== backward-shift deletion, hashmap_robinhood.hpp:1294-1356).
+// LP: tombstone in place (info = 0x80), hashmap_linearprobe.hpp:911-978.
+// A key listed twice in the batch erases once: the atomic decides who counts it.
+template <int KIND, int HASH>
+__global__ void k_erase_mark(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, uint64_t seed,
+                             uint32_t* __restrict__ erased_bits, unsigned long long* __restrict__ n_erased) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t mask = T.cap - 1;
+  uint32_t mine = 0;
+  for (; i < n; i += stride) {
+    uint64_t key = q[i];
+    uint64_t pos = kh_find_pos<KIND>(T.keys, T.info, mask, kh_hash64<HASH>(key, seed) & mask, key);
+    if (pos == KH_NONE) continue;
+    if (KIND == KHK_RH) {
+      uint32_t bit = 1u << (pos & 31);
+      uint32_t old = atomicOr(&erased_bits[pos >> 5], bit);
+      if (!(old & bit)) ++mine;
+    } else {
+      uint32_t* w = reinterpret_cast<uint32_t*>(T.info) + (pos >> 2);
+      uint32_t sh = (uint32_t)(pos & 3) * 8;
+      uint32_t old = atomicOr(w, 0x80u << sh);
+      if (((old >> sh) & 0xFFu) < 0x40u) ++mine;
+    }
+  }
+  // wave reduction, one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_erased, (unsigned long long)mine);
+}
+
+// overwrite the value of keys that are present (kh_update's second half)
+template <int KIND, int HASH>
+__global__ void k_assign_existing(KhSlots T, const uint64_t* __restrict__ q, const uint32_t* __restrict__ v, uint64_t n, uint64_t seed) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t mask = T.cap - 1;
+  for (; i < n; i += stride) {
+    uint64_t key = q[i];
+    uint64_t pos = kh_find_pos<KIND>(T.keys, T.info, mask, kh_hash64<HASH>(key, seed) & mask, key);
+    if (pos != KH_NONE) T.vals[pos] = v[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stream compaction of find hits (find(Iter,Iter) returns only the hits, in query order)
+// ---------------------------------------------------------------------------------------------
+#define KH_CMP_TILE 2048
+__global__ void k_flag_tile_sums(const uint8_t* __restrict__ flags, uint64_t n, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t wsum[4];
+  uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE;
+  uint32_t c = 0;
+  for (uint32_t j = threadIdx.x; j < KH_CMP_TILE; j += 256) {
+    uint64_t i = base + j;
+    if (i < n && flags[i]) ++c;
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// single-workgroup exclusive scan of u32 counts into u64 offsets (out has n+1 entries; out[n] = total)
+__global__ void k_scan_u32_to_u64(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
+  __shared__ uint64_t wtot[16];
+  __shared__ uint64_t carry_s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < n; base += 1024) {
+    uint64_t i = base + tid;
+    uint64_t v = i < n ? in[i] : 0;
+    uint64_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      uint64_t o = __shfl_up(incl, off, 64);
+      if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == 63) wtot[wid] = incl;
+    __syncthreads();
+    uint64_t wpre = 0;
+    for (uint32_t w = 0; w < wid; ++w) wpre += wtot[w];
+    uint64_t carry = carry_s;
+    if (i < n) out[i] = carry + wpre + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wpre + incl;
+    __syncthreads();
+  }
+  if (tid == 0) out[n] = carry_s;
+}
+
+__global__ void k_compact_hits(const uint8_t* __restrict__ flags, const uint64_t* __restrict__ q, const uint32_t* __restrict__ vals,
+                               uint64_t n, const uint64_t* __restrict__ tile_off,
+                               uint64_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals, uint8_t* __restrict__ out_pairs16) {
+  // one 256-thread workgroup per KH_CMP_TILE queries; each lane owns 8 consecutive queries so that
+  // the hit order inside the tile is the query order.
+  __shared__ uint32_t wtot[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE + (uint64_t)tid * 8;
+  uint32_t c = 0;
+  uint8_t f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { uint64_t i = base + j; f[j] = (i < n) ? flags[i] : 0; c += f[j] ? 1 : 0; }
+  uint32_t incl = c;
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t o = __shfl_up(incl, off, 64);
+    if (lane >= (uint32_t)off) incl += o;
+  }
+  if (lane == 63) wtot[wid] = incl;
+  __syncthreads();
+  uint32_t wpre = 0;
+  for (uint32_t w = 0; w < wid; ++w) wpre += wtot[w];
+  uint64_t pos = tile_off[blockIdx.x] + wpre + incl - c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (f[j]) {
+      uint64_t i = base + j;
+      if (out_pairs16) {
+        *reinterpret_cast<uint64_t*>(out_pairs16 + pos * 16) = q[i];
+        *reinterpret_cast<uint32_t*>(out_pairs16 + pos * 16 + 8) = vals[i];
+        *reinterpret_cast<uint32_t*>(out_pairs16 + pos * 16 + 12) = 0;
+      } else {
+        out_keys[pos] = q[i];
+        out_vals[pos] = vals[i];
+      }
+      ++pos;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// radix partition of a batch by (bit-reversed) chunk id.  Records travel as SoA (key, val, idx).
+// ---------------------------------------------------------------------------------------------
+struct KhTile { uint64_t beg; uint32_t len; uint32_t seg; };
+
+struct KhPartParams {
+  const char* kbase; uint32_t kstride;     // input keys (stride 8 = SoA, 16 = pair array)
+  const char* vbase; uint32_t vstride;     // input values (may be null: value = 0)
+  const uint32_t* idx;                     // input original index (null: position)
+  uint64_t n;                              // number of input records
+  const KhTile* tiles;                     // null: arithmetic tiles of KH_PART_TILE over [0,n), seg 0
+  const uint32_t* ntiles_dev;              // with tiles: actual tile count
+  uint32_t ntiles;                         // without tiles: tile count
+  uint64_t seed;
+  uint32_t PB;                             // total partition bits
+  uint32_t shift;                          // digit = (q >> shift) & (nb-1)
+  uint32_t nb;                             // bins in this pass (power of two, <= 2048)
+  uint32_t* counts;                        // [nseg*nb] histogram (hist kernel)
+  unsigned long long* cursor;              // [nseg*nb] running output offsets (scatter kernel)
+  uint64_t* ok; uint32_t* ov; uint32_t* oi;// output records
+};
+
+// partition id of a hash: chunk id at the partitioning capacity, bit-reversed so that the
+// partitions belonging to one chunk of ANY smaller power-of-two capacity are contiguous.
+__device__ __forceinline__ uint32_t kh_part_q(uint64_t h, uint32_t PB) {
+  if (PB == 0) return 0;
+  uint32_t p = (uint32_t)(h >> KH_LB) & ((1u << PB) - 1u);
+  return __brev(p) >> (32 - PB);
+}
+
+__device__ __forceinline__ KhTile kh_get_tile(const KhPartParams& P, uint32_t t) {
+  if (P.tiles) return P.tiles[t];
+  KhTile d;
+  d.beg = (uint64_t)t * KH_PART_TILE;
+  uint64_t rem = P.n - d.beg;
+  d.len = rem < KH_PART_TILE ? (uint32_t)rem : KH_PART_TILE;
+  d.seg = 0;
+  return d;
+}
+
+template <int HASH>
+__global__ __launch_bounds__(KH_PART_THREADS) void k_part_hist(KhPartParams P) {
+  extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
+  uint32_t* hist = kh_dyn_smem;
+  const uint32_t tid = threadIdx.x, nb = P.nb;
+  const uint32_t ntiles = P.tiles ? *P.ntiles_dev : P.ntiles;
+  for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) hist[i] = 0;
+  __syncthreads();
+  const uint32_t tpb = (ntiles + gridDim.x - 1) / gridDim.x;
+  const uint32_t t0 = blockIdx.x * tpb;
+  const uint32_t t1 = (t0 + tpb < ntiles) ? t0 + tpb : ntiles;
+  uint32_t cur_seg = 0xFFFFFFFFu;
+  for (uint32_t t = t0; t < t1; ++t) {
+    KhTile d = kh_get_tile(P, t);
+    if (d.seg != cur_seg) {
+      if (cur_seg != 0xFFFFFFFFu) {
+        __syncthreads();
+        for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) {
+          uint32_t c = hist[i];
+          if (c) { atomicAdd(&P.counts[(uint64_t)cur_seg * nb + i], c); hist[i] = 0; }
+        }
+        __syncthreads();
+      }
+      cur_seg = d.seg;
+    }
+    for (uint32_t i = tid; i < d.len; i += KH_PART_THREADS) {
+      uint64_t key = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
+      uint32_t q = kh_part_q(kh_hash64<HASH>(key, P.seed), P.PB);
+      atomicAdd(&hist[(q >> P.shift) & (nb - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  if (cur_seg != 0xFFFFFFFFu)
+    for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) {
+      uint32_t c = hist[i];
+      if (c) atomicAdd(&P.counts[(uint64_t)cur_seg * nb + i], c);
+    }
+}
+
+template <int HASH>
+__global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P) {
+  extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
+  const uint32_t nb = P.nb;
+  uint32_t* hist = kh_dyn_smem;
+  unsigned long long* base = reinterpret_cast<unsigned long long*>(kh_dyn_smem + ((nb + 1u) & ~1u));
+  const uint32_t tid = threadIdx.x;
+  const uint32_t ntiles = P.tiles ? *P.ntiles_dev : P.ntiles;
+  if (blockIdx.x >= ntiles) return;
+  KhTile d = kh_get_tile(P, blockIdx.x);
+  for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) hist[i] = 0;
+  __syncthreads();
+  uint64_t key[KH_PART_ITEMS];
+  uint32_t dg[KH_PART_ITEMS], rk[KH_PART_ITEMS];
+#pragma unroll
+  for (int j = 0; j < KH_PART_ITEMS; ++j) {
+    uint32_t i = tid + j * KH_PART_THREADS;
+    if (i < d.len) {
+      key[j] = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
+      uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
+      dg[j] = (q >> P.shift) & (nb - 1);
+      rk[j] = atomicAdd(&hist[dg[j]], 1u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) {
+    uint32_t c = hist[i];
+    if (c) base[i] = atomicAdd(&P.cursor[(uint64_t)d.seg * nb + i], (unsigned long long)c);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < KH_PART_ITEMS; ++j) {
+    uint32_t i = tid + j * KH_PART_THREADS;
+    if (i < d.len) {
+      uint64_t pos = base[dg[j]] + rk[j];
+      P.ok[pos] = key[j];
+      P.ov[pos] = P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : 0u;
+      P.oi[pos] = P.idx ? P.idx[d.beg + i] : (uint32_t)(d.beg + i);
+    }
+  }
+}
+
+// tiles of KH_PART_TILE records that never straddle a segment (second partition pass)
+__global__ void k_make_tiles(const uint64_t* __restrict__ segoff, uint32_t nseg, KhTile* __restrict__ tiles, uint32_t* __restrict__ ntiles_out) {
+  __shared__ uint32_t wtot[16];
+  __shared__ uint32_t carry_s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nseg; base += 1024) {
+    uint32_t s = base + tid;
+    uint64_t beg = 0, len = 0;
+    if (s < nseg) { beg = segoff[s]; len = segoff[s + 1] - beg; }
+    uint32_t nt = (uint32_t)((len + KH_PART_TILE - 1) / KH_PART_TILE);
+    uint32_t incl = nt;
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(incl, off, 64);
+      if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == 63) wtot[wid] = incl;
+    __syncthreads();
+    uint32_t wpre = 0;
+    for (uint32_t w = 0; w < wid; ++w) wpre += wtot[w];
+    uint32_t carry = carry_s;
+    uint32_t first = carry + wpre + incl - nt;
+    for (uint32_t k = 0; k < nt; ++k) {
+      KhTile d;
+      d.beg = beg + (uint64_t)k * KH_PART_TILE;
+      uint64_t rem = len - (uint64_t)k * KH_PART_TILE;
+      d.len = rem < KH_PART_TILE ? (uint32_t)rem : KH_PART_TILE;
+      d.seg = s;
+      tiles[first + k] = d;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wpre + incl;
+    __syncthreads();
+  }
+  if (tid == 0) *ntiles_out = carry_s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: per-partition first-wins de-duplication in LDS + membership test against the current table.
+// Emits the batch's DISTINCT NEW keys (with the value of their first occurrence).
+// ---------------------------------------------------------------------------------------------
+struct KhDedupParams {
+  const uint64_t* rk; const uint32_t* rv; const uint32_t* ri;   // partitioned records
+  const uint64_t* part_off;                                      // [nparts+1]
+  uint64_t* nk; uint32_t* nv; uint32_t* ni;                      // outputs, written at part_off[q] + j
+  uint32_t* cnt_new;                                             // [nparts]
+  unsigned long long* max_idx_plus1;                             // max (first-occurrence index + 1) over new keys
+  KhSlots T; uint64_t seed;
+  int last_wins;                                                 // 0: insert (first value wins, emit keys the table lacks)
+                                                                 // 1: kh_update assign pass (last value wins, written in place)
+  uint32_t* flags;
+};
+
+template <int KIND, int HASH>
+__global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
+  __shared__ unsigned long long skey[KH_HS];
+  __shared__ unsigned long long siv[KH_HS];
+  __shared__ unsigned long long special_iv;
+  __shared__ uint32_t out_count, overflow, max_idx;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  const uint64_t beg = P.part_off[q];
+  const uint32_t m = (uint32_t)(P.part_off[q + 1] - beg);
+  const uint64_t mask = P.T.cap - 1;
+  const unsigned long long iv_init = P.last_wins ? 0ull : ~0ull;
+  if (m == 0) { if (tid == 0) P.cnt_new[q] = 0; return; }
+  uint32_t R = (m + KH_HS / 2 - 1) / (KH_HS / 2);   // classes: at most HS/2 records each on average
+  bool done = false;
+  while (!done) {
+    if (tid == 0) { out_count = 0; overflow = 0; max_idx = 0; }
+    for (uint32_t r = 0; r < R; ++r) {
+      for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) { skey[s] = KH_EMPTY_KEY; siv[s] = iv_init; }
+      if (tid == 0) special_iv = iv_init;
+      __syncthreads();
+      for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) {
+        unsigned long long key = P.rk[beg + i];
+        uint64_t f = kh_fmix64(key + 0x9E3779B97F4A7C15ull);
+        if (R > 1 && (uint32_t)((f >> 32) % R) != r) continue;
+        // with last_wins the priority is idx+1 (so that 0 means "none"); idx < 2^32-1 is enforced by the host
+        unsigned long long iv = ((unsigned long long)(P.ri[beg + i] + (P.last_wins ? 1u : 0u)) << 32) | P.rv[beg + i];
+        if (key == KH_EMPTY_KEY) {
+          if (P.last_wins) atomicMax(&special_iv, iv); else atomicMin(&special_iv, iv);
+          continue;
+        }
+        uint32_t slot = (uint32_t)f & (KH_HS - 1);
+        uint32_t probe = 0;
+        for (; probe < KH_HS; ++probe) {
+          unsigned long long cur = skey[slot];
+          if (cur == KH_EMPTY_KEY) cur = atomicCAS(&skey[slot], KH_EMPTY_KEY, key), cur = (cur == KH_EMPTY_KEY) ? key : cur;
+          if (cur == key) {
+            if (P.last_wins) atomicMax(&siv[slot], iv); else atomicMin(&siv[slot], iv);
+            break;
+          }
+          slot = (slot + 1) & (KH_HS - 1);
+        }
+        if (probe == KH_HS) overflow = 1;
+      }
+      __syncthreads();
+      if (overflow) break;
+      // emit distinct keys of this class that the table does not hold yet
+      for (uint32_t s = tid; s < KH_HS + 1; s += KH_CHUNK_THREADS) {
+        unsigned long long key, iv;
+        if (s < KH_HS) { key = skey[s]; iv = siv[s]; if (key == KH_EMPTY_KEY) continue; }
+        else { key = KH_EMPTY_KEY; iv = special_iv; if (iv == iv_init) continue; }
+        uint64_t h = kh_hash64<HASH>(key, P.seed);
+        uint64_t at = kh_find_pos<KIND>(P.T.keys, P.T.info, mask, h & mask, key);
+        if (P.last_wins) {   // kh_update's assign pass: every key is present by now; store its LAST value
+          if (at != KH_NONE) P.T.vals[at] = (uint32_t)iv;
+          continue;
+        }
+        if (at != KH_NONE) continue;
+        uint32_t pos = atomicAdd(&out_count, 1u);
+        uint32_t idx = (uint32_t)(iv >> 32) - (P.last_wins ? 1u : 0u);
+        P.nk[beg + pos] = key;
+        P.nv[beg + pos] = (uint32_t)iv;
+        P.ni[beg + pos] = idx;
+        atomicMax(&max_idx, idx + 1u);   // only meaningful for first-wins (insert)
+      }
+      __syncthreads();
+    }
+    if (overflow) { R *= 2; __syncthreads(); if (R > m) { if (tid == 0) atomicOr(&P.flags[KH_FLAG_INTERNAL], 1u); break; } }
+    else done = true;
+  }
+  if (tid == 0) {
+    P.cnt_new[q] = out_count;
+    if (out_count) atomicMax(P.max_idx_plus1, (unsigned long long)max_idx);
+  }
+}
+
+// gather the per-partition outputs of k_dedup into one contiguous list (partition order)
+__global__ void k_gather_new(const uint64_t* __restrict__ part_off, const uint64_t* __restrict__ noff,
+                             const uint64_t* __restrict__ nk, const uint32_t* __restrict__ nv,
+                             uint64_t* __restrict__ ck, uint32_t* __restrict__ cv) {
+  const uint32_t q = blockIdx.x;
+  const uint64_t src = part_off[q], dst = noff[q];
+  const uint32_t c = (uint32_t)(noff[q + 1] - dst);
+  for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) { ck[dst + i] = nk[src + i]; cv[dst + i] = nv[src + i]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// chunk rebuild: K2a count homes + chunk summary, K2b carry scan over chunks, K3 placement
+// ---------------------------------------------------------------------------------------------
+struct KhRebuildParams {
+  KhSlots Old;                       // source table
+  const uint32_t* erased_bits;       // optional: slots to drop (RH erase)
+  KhSlots New;                       // destination table (info pre-set to "empty")
+  const uint64_t* ck; const uint32_t* cv;   // new distinct elements, partition order
+  const uint64_t* noff;              // [nparts+1] offsets into ck/cv (null: no new elements)
+  uint32_t PB;                       // partition bits the new elements were grouped with
+  uint64_t seed;
+  uint16_t* homecnt;                 // [New.cap] elements per home bucket
+  long long* sumA; long long* sumN;  // per-chunk (max,+) summary, absolute positions
+  const long long* xcarry;           // per-chunk carry-in (absolute first free position)
+  uint32_t* flags;
+};
+
+__device__ __forceinline__ uint32_t kh_log2u(uint64_t x) { return 63u - (uint32_t)__clzll((long long)x); }
+
+// Calls f(key, val, home_new) for every live element of the OLD table whose new home lies in new
+// chunk c.  Elements with old home in old chunk o sit in [S_o, first empty slot at/after S_o + L).
+template <int KIND, int HASH, typename F>
+__device__ __forceinline__ void kh_for_each_old(const KhRebuildParams& P, uint32_t c, uint32_t* s_emin, F f) {
+  const uint32_t tid = threadIdx.x;
+  const uint64_t cap_o = P.Old.cap, mask_o = cap_o - 1, mask_n = P.New.cap - 1;
+  const uint32_t nch_o = cap_o > KH_L ? (uint32_t)(cap_o >> KH_LB) : 1u;
+  const uint32_t nch_n = P.New.cap > KH_L ? (uint32_t)(P.New.cap >> KH_LB) : 1u;
+  const uint32_t Lo = cap_o > KH_L ? KH_L : (uint32_t)cap_o;
+  const uint32_t spill_max = (cap_o - Lo) < KH_L ? (uint32_t)(cap_o - Lo) : KH_L;
+  uint32_t o = nch_o >= nch_n ? c : (c & (nch_o - 1));
+  const uint32_t ostep = nch_o >= nch_n ? nch_n : nch_o;   // second form: exactly one iteration
+  for (; o < nch_o; o += ostep) {
+    const uint64_t S = (uint64_t)o * Lo;
+    __syncthreads();
+    if (tid == 0) *s_emin = spill_max;
+    __syncthreads();
+    for (uint32_t t = tid; t < spill_max; t += KH_CHUNK_THREADS) {
+      if (kh_is_empty<KIND>(P.Old.info[(S + Lo + t) & mask_o])) { atomicMin(s_emin, t); break; }
+    }
+    __syncthreads();
+    const uint32_t e = *s_emin;
+    if (e == spill_max && spill_max > 0 && tid == 0) {
+      // no empty slot within a whole chunk after this one: only possible for clusters longer than KH_L
+      if (spill_max == KH_L) atomicOr(&P.flags[KH_FLAG_REGION_OVERFLOW], 1u);
+    }
+    const uint32_t len = Lo + e;
+    for (uint32_t t = tid; t < len; t += KH_CHUNK_THREADS) {
+      const uint64_t s = (S + t) & mask_o;
+      if (!kh_is_occupied<KIND>(P.Old.info[s])) continue;
+      if (P.erased_bits && ((P.erased_bits[s >> 5] >> (s & 31)) & 1u)) continue;
+      const uint64_t key = P.Old.keys[s];
+      const uint64_t h = kh_hash64<HASH>(key, P.seed);
+      if ((uint32_t)((h & mask_o) >> KH_LB) != o) continue;          // belongs to a neighbouring old chunk
+      if ((uint32_t)((h & mask_n) >> KH_LB) != c) continue;          // goes to another new chunk (growing)
+      f(key, P.Old.vals[s], h & mask_n);
+    }
+    if (nch_o < nch_n) break;
+  }
+  __syncthreads();
+}
+
+// range of the contiguous new-element list that belongs to new chunk c
+__device__ __forceinline__ void kh_new_range(const KhRebuildParams& P, uint32_t c, uint64_t& b, uint64_t& e) {
+  if (!P.noff) { b = e = 0; return; }
+  const uint32_t nch_n = P.New.cap > KH_L ? (uint32_t)(P.New.cap >> KH_LB) : 1u;
+  const uint32_t k = kh_log2u(nch_n);
+  const uint32_t span_bits = P.PB - k;                    // PB >= k by construction
+  const uint32_t q0 = k ? ((__brev(c) >> (32 - k)) << span_bits) : 0u;
+  b = P.noff[q0];
+  e = P.noff[q0 + (1u << span_bits)];
+}
+
+// (max,+) composite: f(x) = max(A, x + n); combine(first, then) = then o first
+struct KhMP { long long A; long long n; };
+#define KH_MP_NEG (-(1ll << 60))
+__device__ __forceinline__ KhMP kh_mp_combine(KhMP first, KhMP then) {
+  KhMP r;
+  long long a = first.A + then.n;
+  r.A = then.A > a ? then.A : a;
+  r.n = first.n + then.n;
+  return r;
+}
+// exclusive scan of per-thread composites over the workgroup (thread order); also returns the total
+__device__ __forceinline__ KhMP kh_block_scan_mp(KhMP v, KhMP* s_wtot, KhMP* total) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  KhMP incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    KhMP o;
+    o.A = __shfl_up(incl.A, off, 64);
+    o.n = __shfl_up(incl.n, off, 64);
+    if (lane >= (uint32_t)off) incl = kh_mp_combine(o, incl);
+  }
+  KhMP excl;
+  excl.A = __shfl_up(incl.A, 1, 64);
+  excl.n = __shfl_up(incl.n, 1, 64);
+  if (lane == 0) { excl.A = KH_MP_NEG; excl.n = 0; }
+  __syncthreads();
+  if (lane == 63) s_wtot[wid] = incl;
+  __syncthreads();
+  KhMP wpre; wpre.A = KH_MP_NEG; wpre.n = 0;
+  for (uint32_t w = 0; w < wid; ++w) wpre = kh_mp_combine(wpre, s_wtot[w]);
+  if (total) {
+    KhMP t = wpre;
+    for (uint32_t w = wid; w < nw; ++w) t = kh_mp_combine(t, s_wtot[w]);
+    *total = t;
+  }
+  return kh_mp_combine(wpre, excl);
+}
+
+#define KH_HOMES_PER_THREAD (KH_L / KH_CHUNK_THREADS)
+
+template <int KIND, int HASH>
+__global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_count(KhRebuildParams P) {
+  __shared__ uint32_t cnt[KH_L];
+  __shared__ uint32_t s_emin;
+  __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
+  const uint32_t tid = threadIdx.x, c = blockIdx.x;
+  const uint32_t Ln = P.New.cap > KH_L ? KH_L : (uint32_t)P.New.cap;
+  const uint64_t Sc = (uint64_t)c * Ln, mask_n = P.New.cap - 1;
+  for (uint32_t i = tid; i < KH_L; i += KH_CHUNK_THREADS) cnt[i] = 0;
+  __syncthreads();
+  kh_for_each_old<KIND, HASH>(P, c, &s_emin, [&](uint64_t, uint32_t, uint64_t hn) { atomicAdd(&cnt[hn - Sc], 1u); });
+  uint64_t nb, ne;
+  kh_new_range(P, c, nb, ne);
+  for (uint64_t i = nb + tid; i < ne; i += KH_CHUNK_THREADS) {
+    uint64_t hn = kh_hash64<HASH>(P.ck[i], P.seed) & mask_n;
+    atomicAdd(&cnt[hn - Sc], 1u);
+  }
+  __syncthreads();
+  // per-thread composite over its consecutive homes, relative to the chunk start
+  KhMP v; v.A = KH_MP_NEG; v.n = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+    uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+    if (b < Ln) {
+      uint32_t cb = cnt[b];
+      if (cb > 0xFFFFu) { atomicOr(&P.flags[KH_FLAG_COUNT_OVERFLOW], 1u); cb = 0xFFFFu; }
+      P.homecnt[Sc + b] = (uint16_t)cb;
+      KhMP h; h.A = (long long)b + cb; h.n = cb;
+      v = kh_mp_combine(v, h);
+    }
+  }
+  KhMP total;
+  kh_block_scan_mp(v, s_wtot, &total);
+  if (tid == 0) { P.sumA[c] = (long long)Sc + total.A; P.sumN[c] = total.n; }
+}
+
+// K2b: one workgroup scans the chunk summaries.  x[c] = absolute first free position entering chunk c.
+// The table is circular: the run-over of the last chunk enters chunk 0, so the prefix composites are
+// applied to x0 = max(0, F_all(0) - cap) (a fixed point as long as one slot of the table stays free).
+__global__ void k_chunk_carry(const long long* __restrict__ sumA, const long long* __restrict__ sumN, uint32_t nch, long long cap,
+                              long long* __restrict__ xcarry, KhMP* __restrict__ prefix_tmp) {
+  __shared__ KhMP s_wtot[16];
+  __shared__ KhMP s_carry;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) { s_carry.A = KH_MP_NEG; s_carry.n = 0; }
+  __syncthreads();
+  for (uint32_t base = 0; base < nch; base += 1024) {
+    uint32_t c = base + tid;
+    KhMP v; v.A = KH_MP_NEG; v.n = 0;
+    if (c < nch) { v.A = sumA[c]; v.n = sumN[c]; }
+    KhMP total;
+    KhMP excl = kh_block_scan_mp(v, s_wtot, &total);
+    KhMP carry = s_carry;
+    if (c < nch) prefix_tmp[c] = kh_mp_combine(carry, excl);
+    __syncthreads();
+    if (tid == 0) s_carry = kh_mp_combine(carry, total);
+    __syncthreads();
+  }
+  KhMP all = s_carry;
+  long long end0 = all.A > all.n ? all.A : all.n;   // F_all(0)
+  long long x0 = end0 - cap;
+  if (x0 < 0) x0 = 0;
+  for (uint32_t c = tid; c < nch; c += 1024) {
+    KhMP p = prefix_tmp[c];
+    long long x = x0 + p.n;
+    xcarry[c] = p.A > x ? p.A : x;
+  }
+}
+
+template <int KIND, int HASH>
+__global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParams P) {
+  __shared__ uint32_t fill[KH_L];
+  __shared__ uint32_t start[KH_L];
+  __shared__ uint32_t s_emin;
+  __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
+  const uint32_t tid = threadIdx.x, c = blockIdx.x;
+  const uint32_t Ln = P.New.cap > KH_L ? KH_L : (uint32_t)P.New.cap;
+  const uint64_t Sc = (uint64_t)c * Ln, mask_n = P.New.cap - 1;
+  uint32_t cb[KH_HOMES_PER_THREAD];
+  KhMP v; v.A = KH_MP_NEG; v.n = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+    uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+    cb[j] = b < Ln ? P.homecnt[Sc + b] : 0u;
+    if (b < Ln) { KhMP h; h.A = (long long)b + cb[j]; h.n = cb[j]; v = kh_mp_combine(v, h); }
+    fill[tid * KH_HOMES_PER_THREAD + j] = 0;
+  }
+  KhMP excl = kh_block_scan_mp(v, s_wtot, nullptr);
+  long long xr = P.xcarry[c] - (long long)Sc;          // carry-in relative to the chunk start (<= 0: none)
+  long long p = excl.A > xr + excl.n ? excl.A : xr + excl.n;
+#pragma unroll
+  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+    uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+    if (b < Ln) {
+      long long st = p > (long long)b ? p : (long long)b;
+      start[b] = (uint32_t)st;
+      p = st + cb[j];
+    }
+  }
+  __syncthreads();
+  auto place = [&](uint64_t key, uint32_t val, uint64_t hn) {
+    uint32_t b = (uint32_t)(hn - Sc);
+    uint32_t r = atomicAdd(&fill[b], 1u);
+    uint32_t prel = start[b] + r;
+    uint32_t dist = prel - b;
+    uint64_t pos = (Sc + prel) & mask_n;
+    P.New.keys[pos] = key;
+    P.New.vals[pos] = val;
+    if (KIND == KHK_RH) {
+      if (dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
+      P.New.info[pos] = (uint8_t)(0x80u | dist);
+    } else {
+      P.New.info[pos] = 0x00;
+    }
+  };
+  kh_for_each_old<KIND, HASH>(P, c, &s_emin, place);
+  uint64_t nb, ne;
+  kh_new_range(P, c, nb, ne);
+  for (uint64_t i = nb + tid; i < ne; i += KH_CHUNK_THREADS) {
+    uint64_t key = P.ck[i];
+    place(key, P.cv[i], kh_hash64<HASH>(key, P.seed) & mask_n);
+  }
+}
+
+// RH displacement histogram (REPROBE_STAT-style oracle)
+__global__ void k_disp_hist(const uint8_t* __restrict__ info, uint64_t cap, unsigned long long* __restrict__ out128) {
+  __shared__ uint32_t h[128];
+  if (threadIdx.x < 128) h[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < cap; i += stride) { uint32_t b = info[i]; if (b >= 0x80u) atomicAdd(&h[b & 0x7Fu], 1u); }
+  __syncthreads();
+  if (threadIdx.x < 128 && h[threadIdx.x]) atomicAdd(&out128[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// occupied (key,value) pairs in slot order: flags for the generic compaction
+template <int KIND>
+__global__ void k_occupied_flags(const uint8_t* __restrict__ info, uint64_t cap, uint8_t* __restrict__ flags) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < cap; i += stride) flags[i] = kh_is_occupied<KIND>(info[i]) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU sharding: stable partition of (key,value) by rank = hash(key, seed) mod p
+// (distributed_batched_robinhood_map.hpp:513-534 key_to_rank, :632-741 assign_count_permute)
+// ---------------------------------------------------------------------------------------------
+#define KH_SHARD_TILE 2048     // 256 threads x 8 consecutive items
+#define KH_SHARD_MAXR 64
+template <int HASH>
+__device__ __forceinline__ uint32_t kh_rank_of(uint64_t key, uint64_t seed, uint32_t p, uint32_t pmask) {
+  uint64_t h = kh_hash64<HASH>(key, seed);
+  return pmask ? (uint32_t)(h & pmask) : (uint32_t)(h % p);
+}
+template <int HASH>
+__global__ void k_shard_count(const uint64_t* __restrict__ keys, uint64_t n, uint64_t seed, uint32_t p, uint32_t pmask,
+                              uint32_t* __restrict__ tile_counts /* [p][ntiles] */, uint32_t ntiles) {
+  __shared__ uint32_t h[KH_SHARD_MAXR];
+  if (threadIdx.x < KH_SHARD_MAXR) h[threadIdx.x] = 0;
+  __syncthreads();
+  uint64_t base = (uint64_t)blockIdx.x * KH_SHARD_TILE;
+  for (uint32_t j = threadIdx.x; j < KH_SHARD_TILE; j += 256) {
+    uint64_t i = base + j;
+    if (i < n) atomicAdd(&h[kh_rank_of<HASH>(keys[i], seed, p, pmask)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < p) tile_counts[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+template <int HASH>
+__global__ void k_shard_scatter(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n, uint64_t seed,
+                                uint32_t p, uint32_t pmask, const uint64_t* __restrict__ tile_off /* [p][ntiles] exclusive */,
+                                uint32_t ntiles, uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
+  // stable: lane t owns items [8t, 8t+8) of the tile; per rank, an exclusive scan over lanes gives the order
+  __shared__ uint32_t wtot[4][KH_SHARD_MAXR];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  uint64_t base = (uint64_t)blockIdx.x * KH_SHARD_TILE + (uint64_t)tid * 8;
+  uint64_t key[8]; uint32_t rk[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    uint64_t i = base + j;
+    key[j] = i < n ? keys[i] : 0;
+    rk[j] = i < n ? kh_rank_of<HASH>(key[j], seed, p, pmask) : 0xFFFFFFFFu;
+  }
+  for (uint32_t r = 0; r < p; ++r) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c += (rk[j] == r) ? 1u : 0u;
+    uint32_t incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(incl, off, 64);
+      if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == 63) wtot[wid][r] = incl;
+    __syncthreads();
+    uint32_t wpre = 0;
+    for (uint32_t w = 0; w < wid; ++w) wpre += wtot[w][r];
+    uint64_t pos = tile_off[(uint64_t)r * ntiles + blockIdx.x] + wpre + incl - c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (rk[j] == r) {
+        ok[pos] = key[j];
+        if (vals) ov[pos] = vals[base + j];
+        ++pos;
+      }
+    }
+  }
+}

@@ -1,0 +1,850 @@
+// kmerhash_amd.hip -- host side of libkmerhash_amd.so: table state machine + C-ABI (include/kmerhash_amd.h).
+//
+// Host logic restates the reference's *observable* contract (sizes, float load thresholds, the
+// doubling/halving rules, first-value-wins) around the chunked GPU kernels of kh_kernels.h:
+//   insert  : partition batch -> LDS de-dup + membership test (k_dedup) -> exact capacity decision
+//             (hashmap_robinhood.hpp:530 rule, evaluated in closed form) -> chunk rebuild into a fresh
+//             buffer (count -> carry scan -> place).  The old buffer stays valid until the new one is
+//             complete, so a failing batch (probe distance >= 128) leaves the table untouched.
+//   erase   : RH marks hits in a bitmask and rebuilds without them; LP writes tombstones in place.
+//   find/count : direct probing, one query per lane.
+#include "kh_kernels.h"
+#include "../../include/kmerhash_amd.h"
+
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+#include <algorithm>
+
+#define KH_VERSION_STR "kmerhash_amd 0.1 (gfx950)"
+
+namespace {
+
+struct ProfRec { const char* name; hipEvent_t a, b; };
+
+struct Block { char* p; size_t cap; };
+
+}  // namespace
+
+struct kh_table {
+  int kind, hash, device;
+  uint64_t seed;
+  hipStream_t stream;
+  float min_lf, max_lf;
+  uint64_t min_load, max_load, lsize;
+  KhSlots cur, spare;
+  // workspace arena (grow-only, reset per operation)
+  std::vector<Block> blocks;
+  size_t blk, off;
+  uint64_t* hpin;   // pinned host scratch (64 x u64)
+  std::string err;
+  bool prof;
+  std::vector<ProfRec> recs;
+  std::vector<std::pair<std::string, std::pair<double, uint64_t> > > prof_acc;
+};
+
+namespace {
+
+inline uint64_t next_pow2(uint64_t x) {   // math_utils.hpp:64-69 (x<=1 -> 1)
+  if (x <= 1) return 1;
+  return uint64_t(1) << (64 - __builtin_clzll(x - 1));
+}
+inline uint64_t threshold(uint64_t buckets, float lf) {   // hashmap_robinhood.hpp:263,269: float arithmetic
+  return static_cast<uint64_t>(static_cast<float>(buckets) * lf);
+}
+inline uint32_t log2u(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
+
+kh_status fail(kh_table* t, kh_status s, const std::string& msg) {
+  if (t) t->err = msg;
+  return s;
+}
+#define HIPCHK(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (call);                                                                           \
+    if (e__ != hipSuccess)                                                                             \
+      return fail(t, e__ == hipErrorOutOfMemory ? KH_ERR_NOMEM : KH_ERR_HIP,                          \
+                  std::string(#call) + ": " + hipGetErrorString(e__));                                \
+  } while (0)
+
+// ---- workspace arena ---------------------------------------------------------------------------
+void arena_reset(kh_table* t) { t->blk = 0; t->off = 0; }
+kh_status arena_take(kh_table* t, size_t bytes, void** out) {
+  bytes = (bytes + 255) & ~size_t(255);
+  if (bytes == 0) bytes = 256;
+  while (t->blk < t->blocks.size()) {
+    Block& b = t->blocks[t->blk];
+    if (t->off + bytes <= b.cap) { *out = b.p + t->off; t->off += bytes; return KH_OK; }
+    ++t->blk; t->off = 0;
+  }
+  size_t cap = std::max(bytes, size_t(64) << 20);
+  char* p = nullptr;
+  HIPCHK(hipMalloc(&p, cap));
+  Block b; b.p = p; b.cap = cap;
+  t->blocks.push_back(b);
+  t->blk = t->blocks.size() - 1;
+  t->off = bytes;
+  *out = p;
+  return KH_OK;
+}
+// after an operation: merge a fragmented arena into one block so that the next call of the same
+// size allocates nothing
+void arena_consolidate(kh_table* t) {
+  if (t->blocks.size() <= 1) return;
+  size_t total = 0;
+  for (auto& b : t->blocks) total += b.cap;
+  hipStreamSynchronize(t->stream);
+  for (auto& b : t->blocks) hipFree(b.p);
+  t->blocks.clear();
+  char* p = nullptr;
+  if (hipMalloc(&p, total) == hipSuccess) { Block b; b.p = p; b.cap = total; t->blocks.push_back(b); }
+  arena_reset(t);
+}
+#define TAKE(ptr, type, count)                                                                  \
+  do {                                                                                          \
+    void* p__ = nullptr;                                                                        \
+    kh_status s__ = arena_take(t, sizeof(type) * size_t(count), &p__);                          \
+    if (s__ != KH_OK) return s__;                                                               \
+    ptr = static_cast<type*>(p__);                                                              \
+  } while (0)
+
+// ---- slots ---------------------------------------------------------------------------------------
+uint8_t empty_byte(int kind) { return kind == KHK_RH ? 0x00 : 0x40; }
+void free_slots(KhSlots& s) {
+  if (s.keys) hipFree(s.keys);
+  if (s.vals) hipFree(s.vals);
+  if (s.info) hipFree(s.info);
+  s.keys = nullptr; s.vals = nullptr; s.info = nullptr; s.cap = 0;
+}
+kh_status alloc_slots(kh_table* t, uint64_t cap, KhSlots& s) {
+  s.keys = nullptr; s.vals = nullptr; s.info = nullptr; s.cap = 0;
+  hipError_t e = hipMalloc(&s.keys, std::max<uint64_t>(cap, 8) * 8);
+  if (e == hipSuccess) e = hipMalloc(&s.vals, std::max<uint64_t>(cap, 8) * 4);
+  if (e == hipSuccess) e = hipMalloc(&s.info, cap + 256);
+  if (e != hipSuccess) { free_slots(s); return fail(t, KH_ERR_NOMEM, std::string("table allocation: ") + hipGetErrorString(e)); }
+  s.cap = cap;
+  return KH_OK;
+}
+// a destination buffer of capacity `cap` with every slot marked empty
+kh_status fresh_slots(kh_table* t, uint64_t cap, KhSlots& s) {
+  if (t->spare.cap == cap && t->spare.keys) { s = t->spare; t->spare = KhSlots{nullptr, nullptr, nullptr, 0}; }
+  else {
+    kh_status st = alloc_slots(t, cap, s);
+    if (st != KH_OK) return st;
+  }
+  HIPCHK(hipMemsetAsync(s.info, empty_byte(t->kind), cap + 256, t->stream));
+  return KH_OK;
+}
+void retire_slots(kh_table* t, KhSlots& s) {   // keep one spare buffer for ping-pong rebuilds
+  if (!s.keys) return;
+  if (t->spare.keys) { hipStreamSynchronize(t->stream); free_slots(t->spare); }
+  t->spare = s;
+  s = KhSlots{nullptr, nullptr, nullptr, 0};
+}
+
+// ---- profiling -----------------------------------------------------------------------------------
+struct Launch {
+  kh_table* t; const char* name; hipEvent_t a, b; bool on;
+  Launch(kh_table* t_, const char* n) : t(t_), name(n), a(nullptr), b(nullptr), on(t_ && t_->prof) {
+    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, t->stream); }
+  }
+  ~Launch() {
+    if (on) { hipEventRecord(b, t->stream); ProfRec r; r.name = name; r.a = a; r.b = b; t->recs.push_back(r); }
+  }
+};
+void prof_collect(kh_table* t) {
+  if (t->recs.empty()) return;
+  hipStreamSynchronize(t->stream);
+  for (auto& r : t->recs) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.a, r.b);
+    hipEventDestroy(r.a); hipEventDestroy(r.b);
+    bool found = false;
+    for (auto& a : t->prof_acc) if (a.first == r.name) { a.second.first += ms; a.second.second += 1; found = true; break; }
+    if (!found) t->prof_acc.push_back(std::make_pair(std::string(r.name), std::make_pair(double(ms), uint64_t(1))));
+  }
+  t->recs.clear();
+}
+
+#define KH_SWITCH_HASH(h, ...)                                                        \
+  switch (h) {                                                                        \
+    case KHH_IDENTITY: { constexpr int HASH = KHH_IDENTITY; __VA_ARGS__; } break;     \
+    case KHH_MURMUR3_X86: { constexpr int HASH = KHH_MURMUR3_X86; __VA_ARGS__; } break; \
+    case KHH_MURMUR3_X64: { constexpr int HASH = KHH_MURMUR3_X64; __VA_ARGS__; } break; \
+    default: { constexpr int HASH = KHH_FARM; __VA_ARGS__; } break;                   \
+  }
+#define KH_SWITCH_KIND_HASH(k, h, ...)                                                \
+  if ((k) == KHK_RH) { constexpr int KIND = KHK_RH; KH_SWITCH_HASH(h, __VA_ARGS__) }  \
+  else { constexpr int KIND = KHK_LP; KH_SWITCH_HASH(h, __VA_ARGS__) }
+
+inline uint32_t grid_for(uint64_t n, uint32_t block, uint32_t maxblocks = 256 * 16) {
+  uint64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > maxblocks) g = maxblocks;
+  return (uint32_t)g;
+}
+
+// stage a host array on the device (workspace) or pass a device pointer through
+template <typename T>
+kh_status stage_in(kh_table* t, const void* p, uint64_t n, kh_mem where, const T** out) {
+  if (where == KH_MEM_DEVICE || p == nullptr) { *out = static_cast<const T*>(p); return KH_OK; }
+  T* d = nullptr;
+  TAKE(d, T, n);
+  HIPCHK(hipMemcpyAsync(d, p, sizeof(T) * n, hipMemcpyHostToDevice, t->stream));
+  *out = d;
+  return KH_OK;
+}
+
+// ---- chunk rebuild ---------------------------------------------------------------------------------
+// Lays out (live elements of t->cur, minus `erased`) U (new distinct elements) at capacity new_cap in
+// a fresh buffer and makes it current.  On KH_ERR_* the current table is unchanged.
+kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint32_t* cv, const uint64_t* noff,
+                  uint32_t PB, const uint32_t* erased, uint64_t total_after) {
+  if (total_after > new_cap)
+    return fail(t, KH_ERR_FULL, "table would hold more elements than buckets (no slot to insert into)");
+  KhSlots nw;
+  kh_status st = fresh_slots(t, new_cap, nw);
+  if (st != KH_OK) return st;
+  const uint32_t nch = new_cap > KH_L ? (uint32_t)(new_cap >> KH_LB) : 1u;
+  uint16_t* homecnt; long long *sumA, *sumN, *xcarry; KhMP* ptmp; uint32_t* flags;
+  TAKE(homecnt, uint16_t, new_cap);
+  TAKE(sumA, long long, nch); TAKE(sumN, long long, nch); TAKE(xcarry, long long, nch);
+  TAKE(ptmp, KhMP, nch);
+  TAKE(flags, uint32_t, KH_NFLAGS);
+  HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
+  KhRebuildParams P;
+  P.Old = t->cur; P.erased_bits = erased; P.New = nw; P.ck = ck; P.cv = cv; P.noff = noff; P.PB = PB;
+  P.seed = t->seed; P.homecnt = homecnt; P.sumA = sumA; P.sumN = sumN; P.xcarry = xcarry; P.flags = flags;
+  { Launch L(t, "k_chunk_count");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_count<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, P)); }
+  { Launch L(t, "k_chunk_carry");
+    hipLaunchKernelGGL(k_chunk_carry, dim3(1), dim3(1024), 0, t->stream, sumA, sumN, nch, (long long)new_cap, xcarry, ptmp); }
+  { Launch L(t, "k_chunk_place");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, P)); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(t->hpin, flags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  const uint32_t* f = reinterpret_cast<const uint32_t*>(t->hpin);
+  if (f[KH_FLAG_PROBE_OVERFLOW] || f[KH_FLAG_REGION_OVERFLOW] || f[KH_FLAG_COUNT_OVERFLOW] || f[KH_FLAG_INTERNAL]) {
+    KhSlots tmp = nw;
+    retire_slots(t, tmp);
+    if (f[KH_FLAG_PROBE_OVERFLOW])
+      return fail(t, KH_ERR_PROBE_OVERFLOW, "Robin Hood probe distance would exceed 127 (7-bit info field, hashmap_robinhood.hpp:142-144,556)");
+    if (f[KH_FLAG_REGION_OVERFLOW])
+      return fail(t, KH_ERR_PROBE_OVERFLOW, "cluster longer than one chunk (2048 slots) without an empty slot");
+    if (f[KH_FLAG_COUNT_OVERFLOW])
+      return fail(t, KH_ERR_PROBE_OVERFLOW, "more than 65535 keys share one home bucket");
+    return fail(t, KH_ERR_HIP, "internal: de-duplication set overflow");
+  }
+  KhSlots old = t->cur;
+  t->cur = nw;
+  retire_slots(t, old);
+  t->min_load = threshold(new_cap, t->min_lf);
+  t->max_load = threshold(new_cap, t->max_lf);
+  return KH_OK;
+}
+
+// rehash(b): hashmap_robinhood.hpp:432-464 / hashmap_linearprobe.hpp:324-349
+kh_status do_rehash(kh_table* t, uint64_t b) {
+  uint64_t n = next_pow2(b);
+  if (n == t->cur.cap) return KH_OK;
+  if (t->kind == KHK_RH) {
+    // RH copy() re-inserts through insert(), which doubles whenever size >= max_load (:530):
+    // the capacity that results is the doubling rule applied to lsize distinct inserts from n.
+    uint64_t c = n;
+    if (t->lsize > 0) {
+      if (0 >= threshold(c, t->max_lf)) c <<= 1;
+      while (t->lsize > threshold(c, t->max_lf)) c <<= 1;
+    }
+    n = c;
+    if (n == t->cur.cap) return KH_OK;
+  } else if (t->lsize > n) {
+    return fail(t, KH_ERR_FULL, "ERROR: did not find any place to insert.  should not have happend (hashmap_linearprobe.hpp:408)");
+  }
+  arena_reset(t);
+  kh_status st = rebuild(t, n, nullptr, nullptr, nullptr, 0, nullptr, t->lsize);
+  arena_consolidate(t);
+  return st;
+}
+kh_status do_reserve(kh_table* t, uint64_t n) {   // :421-426 / :313-318
+  if (n > t->max_load) return do_rehash(t, static_cast<uint64_t>(static_cast<float>(n) / t->max_lf));
+  return KH_OK;
+}
+
+// ---- radix partition of a batch by bit-reversed chunk id ------------------------------------------
+struct Partitioned {
+  uint64_t* rk; uint32_t* rv; uint32_t* ri;   // records grouped by partition
+  uint64_t* part_off;                           // [nparts+1]
+  uint32_t PB, nparts;
+  uint64_t* spare_k; uint32_t* spare_v; uint32_t* spare_i;   // a second record buffer (free for outputs)
+};
+
+kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
+                          uint64_t n, uint32_t PB, Partitioned& out) {
+  const uint32_t nparts = 1u << PB;
+  uint64_t *ak, *bk; uint32_t *av, *ai, *bv, *bi;
+  TAKE(ak, uint64_t, n); TAKE(av, uint32_t, n); TAKE(ai, uint32_t, n);
+  TAKE(bk, uint64_t, n); TAKE(bv, uint32_t, n); TAKE(bi, uint32_t, n);
+  const uint32_t B1 = PB <= 11 ? PB : (PB + 1) / 2, B2 = PB - B1;
+  const uint32_t nb1 = 1u << B1, nb2 = 1u << B2;
+  uint32_t* counts1; uint64_t* off1; unsigned long long* cur1;
+  TAKE(counts1, uint32_t, nb1); TAKE(off1, uint64_t, nb1 + 1); TAKE(cur1, unsigned long long, nb1);
+  HIPCHK(hipMemsetAsync(counts1, 0, sizeof(uint32_t) * nb1, t->stream));
+  KhPartParams P;
+  memset(&P, 0, sizeof(P));
+  P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.idx = nullptr; P.n = n;
+  P.tiles = nullptr; P.ntiles_dev = nullptr; P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
+  P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.counts = counts1; P.cursor = cur1;
+  P.ok = ak; P.ov = av; P.oi = ai;
+  const uint32_t hist_grid = std::min<uint32_t>(P.ntiles, 1024);
+  { Launch L(t, "k_part_hist");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(hist_grid), dim3(KH_PART_THREADS), nb1 * 4, t->stream, P)); }
+  { Launch L(t, "k_scan");
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts1, (uint64_t)nb1, off1); }
+  HIPCHK(hipMemcpyAsync(cur1, off1, sizeof(uint64_t) * nb1, hipMemcpyDeviceToDevice, t->stream));
+  { Launch L(t, "k_part_scatter");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 4 + nb1 * 8, t->stream, P)); }
+  if (B2 == 0) {
+    out.rk = ak; out.rv = av; out.ri = ai; out.part_off = off1; out.PB = PB; out.nparts = nparts;
+    out.spare_k = bk; out.spare_v = bv; out.spare_i = bi;
+    HIPCHK(hipGetLastError());
+    return KH_OK;
+  }
+  // second pass inside every first-pass segment
+  const uint32_t max_tiles = (uint32_t)(n / KH_PART_TILE) + nb1 + 1;
+  KhTile* tiles; uint32_t* ntiles_dev; uint32_t* counts2; uint64_t* off2; unsigned long long* cur2;
+  TAKE(tiles, KhTile, max_tiles); TAKE(ntiles_dev, uint32_t, 1);
+  TAKE(counts2, uint32_t, nparts); TAKE(off2, uint64_t, nparts + 1); TAKE(cur2, unsigned long long, nparts);
+  HIPCHK(hipMemsetAsync(counts2, 0, sizeof(uint32_t) * nparts, t->stream));
+  { Launch L(t, "k_make_tiles");
+    hipLaunchKernelGGL(k_make_tiles, dim3(1), dim3(1024), 0, t->stream, off1, nb1, tiles, ntiles_dev); }
+  KhPartParams Q = P;
+  Q.kbase = reinterpret_cast<const char*>(ak); Q.kstride = 8;
+  Q.vbase = reinterpret_cast<const char*>(av); Q.vstride = 4; Q.idx = ai;
+  Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
+  Q.shift = 0; Q.nb = nb2; Q.counts = counts2; Q.cursor = cur2; Q.ok = bk; Q.ov = bv; Q.oi = bi;
+  { Launch L(t, "k_part_hist");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); }
+  { Launch L(t, "k_scan");
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts2, (uint64_t)nparts, off2); }
+  HIPCHK(hipMemcpyAsync(cur2, off2, sizeof(uint64_t) * nparts, hipMemcpyDeviceToDevice, t->stream));
+  { Launch L(t, "k_part_scatter");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 4 + nb2 * 8, t->stream, Q)); }
+  HIPCHK(hipGetLastError());
+  out.rk = bk; out.rv = bv; out.ri = bi; out.part_off = off2; out.PB = PB; out.nparts = nparts;
+  out.spare_k = ak; out.spare_v = av; out.spare_i = ai;
+  return KH_OK;
+}
+
+// capacity after `ncalls` insert() calls that add `dnew` new keys, the last of which first occurs at
+// call index `last_first` (hashmap_robinhood.hpp:530 / hashmap_linearprobe.hpp:439: ONE doubling per
+// call made while size >= max_load, duplicates included).  Precondition: at most one doubling is
+// pending at the start (size < max_load(2*cap)); the caller peels single calls otherwise.
+uint64_t capacity_after(const kh_table* t, uint64_t cap, uint64_t lsize, uint64_t ncalls, uint64_t dnew, uint64_t last_first) {
+  if (ncalls == 0) return cap;
+  uint64_t c = cap;
+  if (lsize >= threshold(c, t->max_lf)) c <<= 1;                 // call 0
+  const uint64_t fin = lsize + dnew;
+  while (fin > threshold(c, t->max_lf)) c <<= 1;                 // thresholds passed on the way: a later new key follows
+  if (dnew > 0 && fin == threshold(c, t->max_lf) && last_first + 1 < ncalls) c <<= 1;   // reached exactly, a later call follows
+  return c;
+}
+
+// core of insert/update for one batch of device-resident input (n < 2^32 - 16)
+kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
+                      uint64_t n, bool update, uint64_t forced_cap, uint64_t* n_new_out) {
+  *n_new_out = 0;
+  if (n == 0) return KH_OK;
+  const uint64_t cap_u = forced_cap ? forced_cap : capacity_after(t, t->cur.cap, t->lsize, n, n, n - 1);
+  const uint32_t PB = cap_u > KH_L ? log2u(cap_u >> KH_LB) : 0u;
+  if (PB > 22) return fail(t, KH_ERR_UNSUPPORTED, "batch would need more than 2^22 partitions");
+  Partitioned R;
+  kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, n, PB, R);
+  if (st != KH_OK) return st;
+  uint32_t* cnt_new; uint64_t* noff; unsigned long long* scal; uint32_t* flags;
+  TAKE(cnt_new, uint32_t, R.nparts); TAKE(noff, uint64_t, R.nparts + 1); TAKE(scal, unsigned long long, 4);
+  TAKE(flags, uint32_t, KH_NFLAGS);
+  HIPCHK(hipMemsetAsync(scal, 0, sizeof(unsigned long long) * 4, t->stream));
+  HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
+  KhDedupParams D;
+  D.rk = R.rk; D.rv = R.rv; D.ri = R.ri; D.part_off = R.part_off;
+  D.nk = R.spare_k; D.nv = R.spare_v; D.ni = R.spare_i; D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
+  D.T = t->cur; D.seed = t->seed; D.last_wins = 0; D.flags = flags;
+  { Launch L(t, "k_dedup");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
+  { Launch L(t, "k_scan");
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, cnt_new, (uint64_t)R.nparts, noff); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(t->hpin, noff + R.nparts, 8, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipMemcpyAsync(t->hpin + 1, scal, 8, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipMemcpyAsync(t->hpin + 2, flags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  const uint64_t dnew = t->hpin[0];
+  const uint64_t last_first = t->hpin[1] ? t->hpin[1] - 1 : 0;
+  if (reinterpret_cast<const uint32_t*>(t->hpin + 2)[KH_FLAG_INTERNAL])
+    return fail(t, KH_ERR_HIP, "internal: de-duplication set overflow");
+  const uint64_t new_cap = forced_cap ? forced_cap : capacity_after(t, t->cur.cap, t->lsize, n, dnew, last_first);
+  if (dnew > 0 || new_cap != t->cur.cap) {
+    uint64_t* ck = nullptr; uint32_t* cv = nullptr;
+    if (dnew > 0) {
+      TAKE(ck, uint64_t, dnew); TAKE(cv, uint32_t, dnew);
+      Launch L(t, "k_gather_new");
+      hipLaunchKernelGGL(k_gather_new, dim3(R.nparts), dim3(256), 0, t->stream, R.part_off, noff, R.spare_k, R.spare_v, ck, cv);
+    }
+    st = rebuild(t, new_cap, ck, cv, dnew > 0 ? noff : nullptr, PB, nullptr, t->lsize + dnew);
+    if (st != KH_OK) return st;
+    t->lsize += dnew;
+  }
+  if (update) {   // update(k,v): existing keys take the value of their LAST occurrence in the batch
+    D.T = t->cur; D.last_wins = 1;
+    Launch L(t, "k_dedup_assign");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D));
+    HIPCHK(hipGetLastError());
+  }
+  *n_new_out = dnew;
+  return KH_OK;
+}
+
+kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void* vals, uint32_t vstride, uint64_t n,
+                    kh_mem where, bool update, uint64_t* n_inserted) {
+  if (n_inserted) *n_inserted = 0;
+  if (n && !keys) return fail(t, KH_ERR_INVALID, "null keys");
+  HIPCHK(hipSetDevice(t->device));
+  arena_reset(t);
+  const char* kb = static_cast<const char*>(keys);
+  const char* vb = static_cast<const char*>(vals);
+  if (where == KH_MEM_HOST && n) {
+    char* d = nullptr;
+    if (kstride == 16) {           // pair array: one copy, values live at +8
+      TAKE(d, char, n * 16);
+      HIPCHK(hipMemcpyAsync(d, keys, n * 16, hipMemcpyHostToDevice, t->stream));
+      kb = d; vb = d + 8;
+    } else {
+      TAKE(d, char, n * 8);
+      HIPCHK(hipMemcpyAsync(d, keys, n * 8, hipMemcpyHostToDevice, t->stream));
+      kb = d;
+      if (vals) {
+        char* dv = nullptr;
+        TAKE(dv, char, n * 4);
+        HIPCHK(hipMemcpyAsync(dv, vals, n * 4, hipMemcpyHostToDevice, t->stream));
+        vb = dv;
+      }
+    }
+  }
+  const size_t keep_blk = t->blk, keep_off = t->off;   // staged input stays; the rest of the arena is reused per sub-batch
+  uint64_t total_new = 0, done = 0;
+  kh_status st = KH_OK;
+  while (done < n && st == KH_OK) {
+    // more than one doubling pending (only after set_max_load_factor / an LP shrink): the reference doubles
+    // once per insert() call, so peel single calls until at most one is pending
+    uint64_t take = n - done;
+    if (t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) take = 1;
+    if (take > 0xFFFFFFF0ull) take = 0xFFFFFFF0ull;    // 32-bit record indices
+    t->blk = keep_blk; t->off = keep_off;
+    uint64_t nn = 0;
+    if (take == 1 && t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) {
+      // single call: exactly one doubling, whatever the load afterwards
+      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, 1, update, t->cur.cap << 1, &nn);
+    } else {
+      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, take, update, 0, &nn);
+    }
+    total_new += nn;
+    done += take;
+  }
+  if (st == KH_OK) st = do_reserve(t, t->lsize);   // trailing reserve(lsize) of insert(Iter,Iter) (:672 / :546): a no-op unless size > max_load
+  if (st == KH_OK) HIPCHK(hipStreamSynchronize(t->stream));
+  arena_consolidate(t);
+  if (n_inserted) *n_inserted = total_new;
+  return st;
+}
+
+// generic compaction: flags/q/vals (device) -> out (device); returns the number of hits
+kh_status compact(kh_table* t, const uint8_t* flags, const uint64_t* q, const uint32_t* vals, uint64_t n,
+                  uint64_t* out_keys, uint32_t* out_vals, uint8_t* out_pairs, uint64_t* n_out) {
+  *n_out = 0;
+  if (n == 0) return KH_OK;
+  const uint64_t ntl = (n + KH_CMP_TILE - 1) / KH_CMP_TILE;
+  uint32_t* sums; uint64_t* offs;
+  TAKE(sums, uint32_t, ntl); TAKE(offs, uint64_t, ntl + 1);
+  { Launch L(t, "k_flag_tile_sums");
+    hipLaunchKernelGGL(k_flag_tile_sums, dim3((uint32_t)ntl), dim3(256), 0, t->stream, flags, n, sums); }
+  { Launch L(t, "k_scan");
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, sums, ntl, offs); }
+  if (out_keys || out_pairs) {
+    Launch L(t, "k_compact_hits");
+    hipLaunchKernelGGL(k_compact_hits, dim3((uint32_t)ntl), dim3(256), 0, t->stream, flags, q, vals, n, offs, out_keys, out_vals, out_pairs);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(t->hpin, offs + ntl, 8, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  *n_out = t->hpin[0];
+  return KH_OK;
+}
+
+kh_status do_find(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint32_t* out_vals, uint8_t* out_found,
+                  uint64_t* out_ckeys, uint32_t* out_cvals, void* out_pairs, bool compacted, uint64_t* n_found) {
+  if (n_found) *n_found = 0;
+  if (n == 0) return KH_OK;
+  if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
+  HIPCHK(hipSetDevice(t->device));
+  arena_reset(t);
+  const uint64_t* q;
+  kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
+  if (st != KH_OK) return st;
+  const bool host = where == KH_MEM_HOST;
+  uint32_t* dv = out_vals; uint8_t* df = out_found;
+  if (host || compacted || !dv) TAKE(dv, uint32_t, n);
+  if (host || compacted || !df) TAKE(df, uint8_t, n);
+  { Launch L(t, "k_find");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH>), dim3(grid_for(n, 256)), dim3(256), 0, t->stream, t->cur, q, n, t->seed, dv, df)); }
+  HIPCHK(hipGetLastError());
+  uint64_t hits = 0;
+  if (!compacted) {
+    if (n_found) { st = compact(t, df, nullptr, nullptr, n, nullptr, nullptr, nullptr, &hits); if (st != KH_OK) return st; }
+    if (host) {
+      // values of misses stay untouched in the caller's buffer: copy through a flag-selective host loop
+      std::vector<uint32_t> hv(n); std::vector<uint8_t> hf(n);
+      HIPCHK(hipMemcpyAsync(hv.data(), dv, n * 4, hipMemcpyDeviceToHost, t->stream));
+      HIPCHK(hipMemcpyAsync(hf.data(), df, n, hipMemcpyDeviceToHost, t->stream));
+      HIPCHK(hipStreamSynchronize(t->stream));
+      for (uint64_t i = 0; i < n; ++i) { if (out_found) out_found[i] = hf[i]; if (hf[i] && out_vals) out_vals[i] = hv[i]; }
+    }
+  } else {
+    uint64_t* ck = out_ckeys; uint32_t* cv = out_cvals; uint8_t* cp = static_cast<uint8_t*>(out_pairs);
+    if (host) {
+      if (out_pairs) TAKE(cp, uint8_t, n * 16);
+      else { TAKE(ck, uint64_t, n); TAKE(cv, uint32_t, n); }
+    }
+    st = compact(t, df, q, dv, n, out_pairs ? nullptr : ck, out_pairs ? nullptr : cv, out_pairs ? cp : nullptr, &hits);
+    if (st != KH_OK) return st;
+    if (host && hits) {
+      if (out_pairs) HIPCHK(hipMemcpyAsync(out_pairs, cp, hits * 16, hipMemcpyDeviceToHost, t->stream));
+      else {
+        HIPCHK(hipMemcpyAsync(out_ckeys, ck, hits * 8, hipMemcpyDeviceToHost, t->stream));
+        HIPCHK(hipMemcpyAsync(out_cvals, cv, hits * 4, hipMemcpyDeviceToHost, t->stream));
+      }
+      HIPCHK(hipStreamSynchronize(t->stream));
+    }
+  }
+  if (n_found) *n_found = hits;
+  arena_consolidate(t);
+  return KH_OK;
+}
+
+// erase_no_resize over a batch; the caller applies the form-specific resize rule
+kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint64_t* n_erased) {
+  *n_erased = 0;
+  if (n == 0) return KH_OK;
+  if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
+  HIPCHK(hipSetDevice(t->device));
+  arena_reset(t);
+  const uint64_t* q;
+  kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
+  if (st != KH_OK) return st;
+  unsigned long long* cnt; uint32_t* bits = nullptr;
+  TAKE(cnt, unsigned long long, 1);
+  HIPCHK(hipMemsetAsync(cnt, 0, 8, t->stream));
+  if (t->kind == KHK_RH) {
+    const uint64_t words = (t->cur.cap + 31) / 32;
+    TAKE(bits, uint32_t, words);
+    HIPCHK(hipMemsetAsync(bits, 0, words * 4, t->stream));
+  }
+  { Launch L(t, "k_erase_mark");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_erase_mark<KIND, HASH>), dim3(grid_for(n, 256)), dim3(256), 0, t->stream, t->cur, q, n, t->seed, bits, cnt)); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(t->hpin, cnt, 8, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  const uint64_t ne = t->hpin[0];
+  if (ne && t->kind == KHK_RH) {
+    st = rebuild(t, t->cur.cap, nullptr, nullptr, nullptr, 0, bits, t->lsize - ne);
+    if (st != KH_OK) return st;
+  }
+  t->lsize -= ne;
+  *n_erased = ne;
+  return KH_OK;
+}
+
+bool valid(const kh_table* t) { return t != nullptr; }
+
+}  // namespace
+
+// ===================================================================================================
+// C ABI
+// ===================================================================================================
+extern "C" {
+
+const char* kh_version(void) { return KH_VERSION_STR; }
+
+kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t val_bytes, kh_hash hash, uint64_t seed,
+                    uint64_t capacity, float min_lf, float max_lf, int device) {
+  if (!out) return KH_ERR_INVALID;
+  *out = nullptr;
+  if (key_bytes != 8 || val_bytes != 4) return KH_ERR_UNSUPPORTED;
+  if ((int)kind < 0 || (int)kind > 1 || (int)hash < 0 || (int)hash > 3) return KH_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KH_ERR_HIP;   // fail loudly: no CPU fallback exists
+  if (device < 0 || device >= ndev) return KH_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return KH_ERR_HIP;
+  kh_table* t = new kh_table();
+  t->kind = (int)kind; t->hash = (int)hash; t->device = device; t->seed = seed; t->stream = nullptr;
+  t->min_lf = min_lf; t->max_lf = max_lf; t->lsize = 0;
+  t->cur = KhSlots{nullptr, nullptr, nullptr, 0}; t->spare = t->cur;
+  t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false;
+  const uint64_t cap = next_pow2(capacity);
+  if (alloc_slots(t, cap, t->cur) != KH_OK) { delete t; return KH_ERR_NOMEM; }
+  if (hipHostMalloc(reinterpret_cast<void**>(&t->hpin), 64 * sizeof(uint64_t)) != hipSuccess) { free_slots(t->cur); delete t; return KH_ERR_NOMEM; }
+  if (hipMemset(t->cur.info, empty_byte(t->kind), cap + 256) != hipSuccess) { free_slots(t->cur); hipHostFree(t->hpin); delete t; return KH_ERR_HIP; }
+  t->min_load = threshold(cap, min_lf);
+  t->max_load = threshold(cap, max_lf);
+  *out = t;
+  return KH_OK;
+}
+
+kh_status kh_destroy(kh_table* t) {
+  if (!t) return KH_OK;
+  hipSetDevice(t->device);
+  hipStreamSynchronize(t->stream);
+  for (auto& r : t->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  free_slots(t->cur); free_slots(t->spare);
+  for (auto& b : t->blocks) hipFree(b.p);
+  if (t->hpin) hipHostFree(t->hpin);
+  delete t;
+  return KH_OK;
+}
+
+kh_status kh_set_stream(kh_table* t, void* s) {
+  if (!valid(t)) return KH_ERR_INVALID;
+  hipStreamSynchronize(t->stream);
+  t->stream = static_cast<hipStream_t>(s);
+  return KH_OK;
+}
+const char* kh_last_error(const kh_table* t) { return t ? t->err.c_str() : "null table"; }
+
+kh_status kh_size(const kh_table* t, uint64_t* out) { if (!t || !out) return KH_ERR_INVALID; *out = t->lsize; return KH_OK; }
+kh_status kh_capacity(const kh_table* t, uint64_t* out) { if (!t || !out) return KH_ERR_INVALID; *out = t->cur.cap; return KH_OK; }
+kh_status kh_get_load_thresholds(const kh_table* t, uint64_t* mn, uint64_t* mx) {
+  if (!t) return KH_ERR_INVALID;
+  if (mn) *mn = t->min_load;
+  if (mx) *mx = t->max_load;
+  return KH_OK;
+}
+kh_status kh_set_min_load_factor(kh_table* t, float f) { if (!t) return KH_ERR_INVALID; t->min_lf = f; t->min_load = threshold(t->cur.cap, f); return KH_OK; }
+kh_status kh_set_max_load_factor(kh_table* t, float f) { if (!t) return KH_ERR_INVALID; t->max_lf = f; t->max_load = threshold(t->cur.cap, f); return KH_OK; }
+kh_status kh_get_load_factors(const kh_table* t, float* mn, float* mx, float* cur) {
+  if (!t) return KH_ERR_INVALID;
+  if (mn) *mn = t->min_lf;
+  if (mx) *mx = t->max_lf;
+  if (cur) *cur = static_cast<float>(t->lsize) / static_cast<float>(t->cur.cap);
+  return KH_OK;
+}
+kh_status kh_clear(kh_table* t) {
+  if (!t) return KH_ERR_INVALID;
+  HIPCHK(hipSetDevice(t->device));
+  t->lsize = 0;
+  HIPCHK(hipMemsetAsync(t->cur.info, empty_byte(t->kind), t->cur.cap + 256, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return KH_OK;
+}
+kh_status kh_reserve(kh_table* t, uint64_t n) { if (!t) return KH_ERR_INVALID; HIPCHK(hipSetDevice(t->device)); return do_reserve(t, n); }
+kh_status kh_rehash(kh_table* t, uint64_t b) { if (!t) return KH_ERR_INVALID; HIPCHK(hipSetDevice(t->device)); return do_rehash(t, b); }
+
+kh_status kh_insert(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted) {
+  if (!t) return KH_ERR_INVALID;
+  return do_insert(t, keys, 8, vals, 4, n, where, false, n_inserted);
+}
+kh_status kh_insert_pairs(kh_table* t, const void* pairs16, uint64_t n, kh_mem where, uint64_t* n_inserted) {
+  if (!t) return KH_ERR_INVALID;
+  return do_insert(t, pairs16, 16, pairs16 ? static_cast<const char*>(pairs16) + 8 : nullptr, 16, n, where, false, n_inserted);
+}
+kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted) {
+  if (!t) return KH_ERR_INVALID;
+  return do_insert(t, keys, 8, vals, 4, n, where, true, n_inserted);
+}
+
+kh_status kh_count(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint8_t* out01) {
+  if (!t) return KH_ERR_INVALID;
+  if (n == 0) return KH_OK;
+  if (!keys || !out01) return fail(t, KH_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  arena_reset(t);
+  const uint64_t* q;
+  kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
+  if (st != KH_OK) return st;
+  uint8_t* d = out01;
+  if (where == KH_MEM_HOST) TAKE(d, uint8_t, n);
+  { Launch L(t, "k_count");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_count<KIND, HASH>), dim3(grid_for(n, 256)), dim3(256), 0, t->stream, t->cur, q, n, t->seed, d)); }
+  HIPCHK(hipGetLastError());
+  if (where == KH_MEM_HOST) {
+    HIPCHK(hipMemcpyAsync(out01, d, n, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+  }
+  arena_consolidate(t);
+  return KH_OK;
+}
+
+kh_status kh_find(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint32_t* out_vals, uint8_t* out_found, uint64_t* n_found) {
+  if (!t) return KH_ERR_INVALID;
+  return do_find(t, keys, n, where, out_vals, out_found, nullptr, nullptr, nullptr, false, n_found);
+}
+kh_status kh_find_compact(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint64_t* out_keys, uint32_t* out_vals, uint64_t* n_found) {
+  if (!t) return KH_ERR_INVALID;
+  if (n && (!out_keys || !out_vals)) return fail(t, KH_ERR_INVALID, "null output");
+  return do_find(t, keys, n, where, nullptr, nullptr, out_keys, out_vals, nullptr, true, n_found);
+}
+kh_status kh_find_compact_pairs(kh_table* t, const void* keys, uint64_t n, kh_mem where, void* out_pairs16, uint64_t* n_found) {
+  if (!t) return KH_ERR_INVALID;
+  if (n && !out_pairs16) return fail(t, KH_ERR_INVALID, "null output");
+  return do_find(t, keys, n, where, nullptr, nullptr, nullptr, nullptr, out_pairs16, true, n_found);
+}
+
+kh_status kh_erase(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint64_t* n_erased) {
+  if (!t) return KH_ERR_INVALID;
+  uint64_t ne = 0;
+  kh_status st = erase_core(t, keys, n, where, &ne);
+  if (n_erased) *n_erased = ne;
+  if (st != KH_OK) { arena_consolidate(t); return st; }
+  if (t->lsize < t->min_load) {
+    if (t->kind == KHK_RH) st = do_reserve(t, t->lsize);   // hashmap_robinhood.hpp:1437: reserve() only grows
+    else st = do_rehash(t, static_cast<uint64_t>(static_cast<float>(t->lsize) / t->max_lf));   // hashmap_linearprobe.hpp:1048
+  }
+  arena_consolidate(t);
+  return st;
+}
+kh_status kh_erase_one(kh_table* t, uint64_t key, uint64_t* n_erased) {
+  if (!t) return KH_ERR_INVALID;
+  uint64_t ne = 0;
+  kh_status st = erase_core(t, &key, 1, KH_MEM_HOST, &ne);
+  if (n_erased) *n_erased = ne;
+  if (st == KH_OK && t->lsize < t->min_load) st = do_rehash(t, t->cur.cap >> 1);   // :1425 / :1036
+  arena_consolidate(t);
+  return st;
+}
+
+kh_status kh_to_vector(kh_table* t, uint64_t* keys_host, uint32_t* vals_host, uint64_t* n_out) {
+  if (!t) return KH_ERR_INVALID;
+  HIPCHK(hipSetDevice(t->device));
+  arena_reset(t);
+  const uint64_t cap = t->cur.cap;
+  uint8_t* flags; uint64_t* ck; uint32_t* cv;
+  TAKE(flags, uint8_t, cap); TAKE(ck, uint64_t, cap); TAKE(cv, uint32_t, cap);
+  { Launch L(t, "k_occupied_flags");
+    if (t->kind == KHK_RH) hipLaunchKernelGGL((k_occupied_flags<KHK_RH>), dim3(grid_for(cap, 256)), dim3(256), 0, t->stream, t->cur.info, cap, flags);
+    else hipLaunchKernelGGL((k_occupied_flags<KHK_LP>), dim3(grid_for(cap, 256)), dim3(256), 0, t->stream, t->cur.info, cap, flags); }
+  uint64_t m = 0;
+  kh_status st = compact(t, flags, t->cur.keys, t->cur.vals, cap, ck, cv, nullptr, &m);
+  if (st != KH_OK) return st;
+  if (m && keys_host) HIPCHK(hipMemcpyAsync(keys_host, ck, m * 8, hipMemcpyDeviceToHost, t->stream));
+  if (m && vals_host) HIPCHK(hipMemcpyAsync(vals_host, cv, m * 4, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (n_out) *n_out = m;
+  arena_consolidate(t);
+  return KH_OK;
+}
+kh_status kh_export_info(kh_table* t, uint8_t* out_host) {
+  if (!t || !out_host) return KH_ERR_INVALID;
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMemcpyAsync(out_host, t->cur.info, t->cur.cap, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return KH_OK;
+}
+kh_status kh_export_slots(kh_table* t, uint64_t* keys_host, uint32_t* vals_host) {
+  if (!t) return KH_ERR_INVALID;
+  HIPCHK(hipSetDevice(t->device));
+  if (keys_host) HIPCHK(hipMemcpyAsync(keys_host, t->cur.keys, t->cur.cap * 8, hipMemcpyDeviceToHost, t->stream));
+  if (vals_host) HIPCHK(hipMemcpyAsync(vals_host, t->cur.vals, t->cur.cap * 4, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return KH_OK;
+}
+kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]) {
+  if (!t || !out) return KH_ERR_INVALID;
+  for (int i = 0; i < 128; ++i) out[i] = 0;
+  if (t->kind != KHK_RH) return KH_OK;
+  HIPCHK(hipSetDevice(t->device));
+  arena_reset(t);
+  unsigned long long* d;
+  TAKE(d, unsigned long long, 128);
+  HIPCHK(hipMemsetAsync(d, 0, 128 * 8, t->stream));
+  { Launch L(t, "k_disp_hist");
+    hipLaunchKernelGGL(k_disp_hist, dim3(grid_for(t->cur.cap, 256, 1024)), dim3(256), 0, t->stream, t->cur.info, t->cur.cap, d); }
+  HIPCHK(hipMemcpyAsync(out, d, 128 * 8, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return KH_OK;
+}
+
+kh_status kh_hash_batch(kh_hash hash, uint64_t seed, const void* keys, uint64_t n, kh_mem where, uint64_t* out, int device, void* stream_) {
+  kh_table* t = nullptr;
+  if (n == 0) return KH_OK;
+  if (!keys || !out || (int)hash < 0 || (int)hash > 3) return KH_ERR_INVALID;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(device));
+  const uint64_t* dk = static_cast<const uint64_t*>(keys);
+  uint64_t* dout = out; uint64_t* tmp = nullptr;
+  if (where == KH_MEM_HOST) {
+    HIPCHK(hipMalloc(&tmp, n * 16));
+    HIPCHK(hipMemcpyAsync(tmp, keys, n * 8, hipMemcpyHostToDevice, stream));
+    dk = tmp; dout = tmp + n;
+  }
+  KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_hash_batch<HASH>), dim3(grid_for(n, 256)), dim3(256), 0, stream, dk, n, seed, dout));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && where == KH_MEM_HOST) e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess && where == KH_MEM_HOST) e = hipStreamSynchronize(stream);
+  if (tmp) hipFree(tmp);
+  return e == hipSuccess ? KH_OK : KH_ERR_HIP;
+}
+
+kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64_t* keys, const uint32_t* vals, uint64_t n,
+                           uint64_t* out_keys, uint32_t* out_vals, uint64_t* counts_host, int device, void* stream_) {
+  kh_table* t = nullptr;
+  if (p == 0 || p > KH_SHARD_MAXR || !counts_host || (int)hash < 0 || (int)hash > 3) return KH_ERR_INVALID;
+  for (uint32_t r = 0; r < p; ++r) counts_host[r] = 0;
+  if (n == 0) return KH_OK;
+  if (!keys || !out_keys || (vals && !out_vals)) return KH_ERR_INVALID;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(device));
+  const uint32_t ntiles = (uint32_t)((n + KH_SHARD_TILE - 1) / KH_SHARD_TILE);
+  const uint32_t pmask = (p & (p - 1)) == 0 ? p - 1 : 0;   // power of two: & (p-1); else % p.  (p == 1: mask 0 -> % 1)
+  uint32_t* tc = nullptr; uint64_t* toff = nullptr;
+  const uint64_t m = (uint64_t)p * ntiles;
+  HIPCHK(hipMalloc(&tc, m * 4));
+  if (hipMalloc(&toff, (m + 1) * 8) != hipSuccess) { hipFree(tc); return KH_ERR_NOMEM; }
+  KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_count<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, n, seed, p, pmask, tc, ntiles));
+  hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, stream, tc, m, toff);
+  KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
+  std::vector<uint64_t> ends(p + 1);
+  hipError_t e = hipGetLastError();
+  for (uint32_t r = 0; r <= p && e == hipSuccess; ++r)
+    e = hipMemcpyAsync(&ends[r], toff + (uint64_t)r * ntiles, 8, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  hipFree(tc); hipFree(toff);
+  if (e != hipSuccess) return KH_ERR_HIP;
+  for (uint32_t r = 0; r < p; ++r) counts_host[r] = ends[r + 1] - ends[r];
+  return KH_OK;
+}
+
+kh_status kh_profile_enable(kh_table* t, int on) { if (!t) return KH_ERR_INVALID; prof_collect(t); t->prof = on != 0; return KH_OK; }
+kh_status kh_profile_reset(kh_table* t) { if (!t) return KH_ERR_INVALID; prof_collect(t); t->prof_acc.clear(); return KH_OK; }
+kh_status kh_profile_query(kh_table* t, const char* prefix, double* total_ms, uint64_t* launches) {
+  if (!t || !prefix) return KH_ERR_INVALID;
+  prof_collect(t);
+  double ms = 0; uint64_t n = 0;
+  const size_t pl = strlen(prefix);
+  for (auto& a : t->prof_acc) if (a.first.compare(0, pl, prefix) == 0) { ms += a.second.first; n += a.second.second; }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  return KH_OK;
+}
+kh_status kh_profile_dump(kh_table* t, char* buf, uint64_t cap) {
+  if (!t || !buf || cap == 0) return KH_ERR_INVALID;
+  prof_collect(t);
+  std::string s;
+  char line[256];
+  for (auto& a : t->prof_acc) {
+    snprintf(line, sizeof(line), "%s %llu %.6f\n", a.first.c_str(), (unsigned long long)a.second.second, a.second.first);
+    s += line;
+  }
+  snprintf(buf, cap, "%s", s.c_str());
+  return KH_OK;
+}
+
+}  // extern "C"

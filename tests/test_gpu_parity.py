@@ -1,0 +1,239 @@
+"""GPU parity tests proper: the HIP tables (through the C-ABI) against the CPU oracle on the same seeded
+inputs.  Integer/byte/index work: every comparison is bit-exact.
+
+What is compared: size, capacity, the Robin Hood info array (canonical: it depends only on
+the key set and the capacity), the sorted (key, first-wins value) set, per-query count, the compacted find
+result in query order, erase counts, post-erase state.  For the LP table the slot layout depends on the
+insertion order in the reference, so results - not layout - are compared.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import kmerhash_amd as kh  # noqa: E402
+from kmerhash_amd import workloads as W  # noqa: E402
+
+KINDS = [("rh", kh.hashmap_robinhood_doubling, 0), ("lp", kh.hashmap_linearprobe_doubling, 1)]
+HASHES = [("murmur3avx64", 1), ("murmur", 2), ("farm", 3), ("identity", 0)]
+
+
+def dev(a):
+    if a.dtype == np.uint64:
+        return torch.from_numpy(a.view(np.int64)).cuda()
+    if a.dtype == np.uint32:
+        return torch.from_numpy(a.view(np.int32)).cuda()
+    return torch.from_numpy(a).cuda()
+
+
+def host(t, dtype):
+    return t.cpu().numpy().view(dtype)
+
+
+def check_state(g, o, kind, layout=True):
+    assert g.size() == o.size()
+    assert g.capacity() == o.capacity()
+    assert g.load_thresholds() == (o.min_load(), o.max_load())
+    gk, gv = g.sorted_items()
+    ok, ov = o.sorted_items()
+    assert np.array_equal(gk, ok)
+    assert np.array_equal(gv, ov)
+    ginfo = g.export_info()
+    oinfo = o.export_info()
+    if kind == 0 and layout:
+        assert np.array_equal(ginfo, oinfo), "Robin Hood info array differs from the oracle"
+        assert np.array_equal(g.displacement_histogram(), o.displacement_histogram())
+    if kind == 1:
+        # same occupied slot set is NOT required for LP (tombstones / order), but the count must agree
+        assert int((ginfo < 0x40).sum()) == o.size()
+    # every occupied slot holds a key whose probe sequence reaches it (self-consistency through count)
+    if g.size():
+        k, _ = g.to_vector()
+        assert g.count(k).all()
+
+
+def check_queries(g, o, q):
+    assert np.array_equal(g.count(q), o.count(q))
+    assert np.array_equal(host(g.count(dev(q)), np.uint8), o.count(q))
+    fk, fv = g.find(dev(q))
+    ok, ov = o.find_compact(q)
+    assert np.array_equal(host(fk, np.uint64), ok)
+    assert np.array_equal(host(fv, np.uint32), ov)
+    fk2, fv2 = g.find(q)
+    assert np.array_equal(fk2, ok) and np.array_equal(fv2, ov)
+    vals, found = g.find_values(q)
+    ovals, ofound = o.find(q)
+    assert np.array_equal(found, ofound)
+    assert np.array_equal(vals[found == 1], ovals[ofound == 1])
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+@pytest.mark.parametrize("hname,hid", HASHES)
+@pytest.mark.parametrize("n", [0, 1, 7, 1000, 100_000])
+def test_insert_find_count_erase(oracle, kname, cls, kind, hname, hid, n):
+    keys, vals = W.w1_benchmark_hashtables(n, seed=23) if n else (np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    if hname == "identity":
+        keys = W.splitmix64(keys)   # identity on clustered k-mers would overflow the 7-bit distance; spread them
+    g = cls(128, 0.35, 0.8, hash=hname, seed=43)
+    o = oracle.OracleTable(kind, 128, 0.35, 0.8, hid, 43)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals)
+    check_state(g, o, kind)
+    q = W.queries_hits_and_misses(keys, max(2 * n // 3, 4), 0.5) if n else W.distinct_u64(5)
+    check_queries(g, o, q)
+    e = q[: len(q) // 2]
+    assert g.erase(dev(e)) == o.erase(e)
+    check_state(g, o, kind)
+    check_queries(g, o, q)
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_incremental_batches_host_arrays(oracle, kname, cls, kind):
+    """several insert batches with overlaps, host (numpy) inputs, growth across many doublings"""
+    g = cls(128, 0.35, 0.8)
+    o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    allk, allv = W.w1_benchmark_hashtables(60_000, seed=5)
+    cuts = [0, 1, 2, 10, 103, 104, 1000, 5000, 30_000, 60_000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert g.insert(allk[a:b], allv[a:b]) == o.insert(allk[a:b], allv[a:b])
+        check_state(g, o, kind)
+    # re-insert everything: all duplicates, first values stay
+    assert g.insert(allk, allv + 7) == o.insert(allk, allv + 7) == 0
+    check_state(g, o, kind)
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_capacity_rule_edges(oracle, kname, cls, kind):
+    """doubling happens on ANY insert call made while size >= max_load, duplicates included
+    (hashmap_robinhood.hpp:530); SURVEY Appendix B: 102 distinct in cap 128 stay, a following duplicate doubles."""
+    keys = W.distinct_u64(300, seed=9)
+    vals = np.arange(300, dtype=np.uint32)
+    for tail in (0, 1):
+        g = cls(128, 0.35, 0.8)
+        o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+        k = np.concatenate([keys[:102], keys[:tail]])
+        v = np.concatenate([vals[:102], vals[:tail] + 900])
+        assert g.insert(k, v) == o.insert(k, v) == 102
+        assert g.capacity() == o.capacity() == (128 if tail == 0 else 256)
+        check_state(g, o, kind)
+        # next batch of one duplicate doubles a table that sits exactly at max_load
+        assert g.insert(keys[:1], vals[:1]) == o.insert(keys[:1], vals[:1]) == 0
+        assert g.capacity() == o.capacity() == 256
+        check_state(g, o, kind)
+        g.close()
+    # the new key that reaches max_load is the LAST call vs. is followed by a duplicate
+    for order in ("last", "followed"):
+        g = cls(128, 0.35, 0.8)
+        o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+        if order == "last":
+            k = np.concatenate([keys[:50], keys[:50], keys[50:102]])
+        else:
+            k = np.concatenate([keys[:102], keys[5:6]])
+        v = np.arange(len(k), dtype=np.uint32)
+        assert g.insert(k, v) == o.insert(k, v)
+        assert g.capacity() == o.capacity()
+        check_state(g, o, kind)
+        g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_erase_shrink_rules(oracle, kname, cls, kind):
+    """erase 100 of 102 via erase(begin,end): RH stays at cap 256, LP shrinks to cap 2."""
+    keys = W.distinct_u64(103, seed=4)
+    vals = np.arange(103, dtype=np.uint32)
+    g = cls(128, 0.35, 0.8)
+    o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    assert g.insert(keys, vals) == o.insert(keys, vals)
+    assert g.capacity() == o.capacity() == 256
+    assert g.erase(keys[:101]) == o.erase(keys[:101]) == 101
+    assert g.capacity() == o.capacity() == (256 if kind == 0 else 2)
+    check_state(g, o, kind)
+    check_queries(g, o, keys)
+    # next insert: the LP table of 2 buckets holding 2 elements doubles on the next call
+    assert g.insert(keys[:5], vals[:5]) == o.insert(keys[:5], vals[:5])
+    check_state(g, o, kind)
+    # single-key erase halves when size < min_load
+    for k in keys[:8]:
+        assert g.erase_one(int(k)) == o.erase_one(int(k))
+        assert g.capacity() == o.capacity()
+    check_state(g, o, kind)
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_update_reserve_rehash_clear(oracle, kname, cls, kind):
+    keys, vals = W.w1_benchmark_hashtables(20_000, seed=77)
+    g = cls(128, 0.35, 0.8)
+    o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    g.reserve(5000); o.reserve(5000)
+    assert g.capacity() == o.capacity()
+    g.insert(keys[:10_000], vals[:10_000]); o.insert(keys[:10_000], vals[:10_000])
+    # update == insert-or-overwrite in batch order (last value wins)
+    g.update(keys[5_000:], vals[5_000:] + 1_000_000)
+    for k, v in zip(keys[5_000:], vals[5_000:] + 1_000_000):
+        o.update_one(int(k), int(v))
+    check_state(g, o, kind)
+    g.rehash(1 << 17); o.rehash(1 << 17)
+    check_state(g, o, kind)
+    g.clear(); o.clear()
+    assert g.size() == o.size() == 0 and g.capacity() == o.capacity()
+    g.insert(keys, vals); o.insert(keys, vals)
+    check_state(g, o, kind)
+    g.close()
+
+
+def test_pairs_layout(oracle):
+    """std::pair<uint64_t,uint32_t> arrays (16 B, value at +8) in and out"""
+    keys, vals = W.w1_benchmark_hashtables(5000, seed=3)
+    pairs = np.zeros((len(keys), 2), dtype=np.uint64)
+    pairs[:, 0] = keys
+    pairs[:, 1] = vals
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    o = oracle.OracleTable(0, 128, 0.35, 0.8)
+    assert g.insert(pairs) == o.insert(keys, vals)
+    check_state(g, o, 0)
+    g2 = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    assert g2.insert(torch.from_numpy(pairs.view(np.int64)).cuda()) == o.size()
+    check_state(g2, o, 0)
+    g.close(); g2.close()
+
+
+def test_probe_overflow_is_refused(oracle):
+    """identity hash on dense small keys drives the probe distance past 127: the reference asserts
+    (hashmap_robinhood.hpp:556) or silently corrupts under NDEBUG; we refuse and keep the table intact."""
+    g = kh.hashmap_robinhood_doubling(1 << 20, 0.35, 0.8, hash="identity")
+    good = W.distinct_u64(1000, seed=8)
+    g.insert(good, np.arange(1000, dtype=np.uint32))
+    bad = (np.arange(200_000, dtype=np.uint64) % np.uint64(1500)) * np.uint64(1 << 20) + np.uint64(77)
+    with pytest.raises(kh.KhError) as ei:
+        g.insert(bad, np.zeros(len(bad), dtype=np.uint32))
+    assert "KH_ERR_PROBE_OVERFLOW" in str(ei.value)
+    assert g.size() == 1000 and g.count(good).all()
+    g.close()
+
+
+def test_hash_batch_matches_oracle(oracle):
+    keys = np.concatenate([np.arange(0, 1003, dtype=np.uint64), W.distinct_u64(10_000, seed=2),
+                           np.array([0xFFFFFFFFFFFFFFFF, 1 << 63, 1], dtype=np.uint64)])
+    for hname, hid in HASHES:
+        for seed in (43, 0, 9876543):
+            got = kh.hash_batch(keys, hash=hname, seed=seed)
+            assert np.array_equal(got, oracle.hash_batch(hid, seed, keys)), (hname, seed)
+            got_d = kh.hash_batch(dev(keys), hash=hname, seed=seed)
+            assert np.array_equal(host(got_d, np.uint64), got)
+
+
+def test_sentinel_key_values(oracle):
+    """0 and 0xFFFF...F are ordinary keys (the LDS de-dup set uses all-ones as its empty marker internally)"""
+    keys = np.array([0, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 1, 0, 2**63], dtype=np.uint64)
+    vals = np.arange(len(keys), dtype=np.uint32)
+    for _, cls, kind in KINDS:
+        g = cls(128, 0.35, 0.8)
+        o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+        assert g.insert(keys, vals) == o.insert(keys, vals) == 4
+        check_state(g, o, kind)
+        check_queries(g, o, np.array([0, 5, 0xFFFFFFFFFFFFFFFF, 2**63, 3], dtype=np.uint64))
+        g.close()
