@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X (BASELINE.json configs[1] at N=1).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one synthetic batch, inputs already resident in HBM:
+    fresh table (capacity 128, min/max load 0.35/0.8, murmur3avx64 seed 43)
+    insert  KEYS_PER_GPU random DISTINCT 64-bit k-mers with 32-bit values (table doubles up to 2^27: load 0.745)
+    find    QUERIES_PER_GPU keys (all hits), compacted (key,value) result in query order
+This is the benchmark_hashmap phase sequence (BenchmarkHashTables.cpp:1037-1186) restricted to the two
+rates BASELINE.json's metric names.  N>1 (weak scaling): every rank generates its own KEYS_PER_GPU pairs,
+keys are sharded by murmur3(key, seed 9876543) & (N-1), exchanged with RCCL all_to_all_single, and inserted
+into the owner's local table; finds travel the same way and results return with the swapped counts.
+
+Rank 0 prints ONE JSON line: metric/value = whole-job k-mer operations (inserts + finds) per second, plus
+the two individual rates, the roofline of the dominant kernel (HIP-event timed inside the library on the
+table's stream) and a CPU baseline of the same workload on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+KEYS_PER_GPU = 100_000_000
+QUERIES_PER_GPU = 10_000_000
+# algorithmic bytes per operation (AoS-equivalent sizes of the reference)
+B_INSERT_NEW, B_INSERT_DUP, B_FIND_HIT, B_FIND_MISS = 50, 33, 41, 9
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def gen_inputs(rank, n, nq):
+    from kmerhash_amd import workloads as W
+    keys = W.distinct_u64(n, seed=1 + rank)          # W2: distinct uniform u64 (bijective splitmix64 of a counter)
+    vals = np.arange(n, dtype=np.uint32)
+    q = keys[:nq].copy()                             # all hits (BenchmarkHashTables.cpp:1062-1066: first N/Q inputs)
+    return keys, vals, q
+
+
+def cpu_baseline(keys, vals, q):
+    """the CPU oracle (own restatement of the reference RH table: kind 'port') timed on one host core, on a
+    bounded sample of the same stream"""
+    from oracle import oracle_py as O
+    n = min(len(keys), 20_000_000)
+    nq = min(len(q), 2_000_000)
+    t = O.OracleTable(O.KIND_RH, 128, 0.35, 0.8, O.HASH_MURMUR3_X86, 43)
+    ti = t.timed_insert(keys[:n], vals[:n])
+    tf, hits = t.timed_find(q[:nq])
+    assert hits == nq
+    return {"value": (n + nq) / (ti + tf), "unit": "kmer_ops/s", "cores": 1, "kind": "port",
+            "sample": "first %d inserts + %d finds of the same stream, oracle RH table (1 thread, g++ -O3)" % (n, nq),
+            "inserts_per_s": n / ti, "finds_per_s": nq / tf}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--keys", type=int, default=KEYS_PER_GPU)
+    ap.add_argument("--queries", type=int, default=QUERIES_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunks", type=int, default=4, help="exchange/insert overlap pieces at N>1")
+    args = ap.parse_args()
+
+    import torch
+    import kmerhash_amd as kh
+    from kmerhash_amd import dist as khd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    keys, vals, q = gen_inputs(rank, args.keys, args.queries)
+    dk = torch.from_numpy(keys.view(np.int64)).to(dev)
+    dv = torch.from_numpy(vals.view(np.int32)).to(dev)
+    dq = torch.from_numpy(q.view(np.int64)).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prof = {}
+    ins_ms, find_ms = [], []
+
+    def one_step(timed):
+        if distributed:
+            be = khd.GpuBackend(local_rank, "rh", 128, 0.35, 0.8, "murmur3avx64", 43)
+            t = khd.ShardedTable(be)
+            table = be.table
+        else:
+            table = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash="murmur3avx64", seed=43, device=local_rank)
+            t = None
+        if timed:
+            table.profile_enable(True)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        if distributed:
+            n_ins = t.insert(dk, dv, chunks=args.chunks)
+        else:
+            n_ins = table.insert(dk, dv)
+        e1.record()
+        if distributed:
+            _, fvals, ffound = t.find(dq)
+            n_hit = int(ffound.sum().item())
+        else:
+            fk, fv = table.find(dq)
+            n_hit = fk.numel()
+        e2.record()
+        torch.cuda.synchronize()
+        if timed:
+            ins_ms.append(e0.elapsed_time(e1))
+            find_ms.append(e1.elapsed_time(e2))
+            for k, (n, ms) in table.profile().items():
+                a = prof.setdefault(k, [0, 0.0])
+                a[0] += n
+                a[1] += ms
+        state = (n_ins, n_hit, table.size(), table.capacity())
+        table.close()
+        return state
+
+    for _ in range(args.warmup):
+        one_step(False)
+    barrier()
+    t0 = time.perf_counter()
+    state = None
+    for _ in range(args.steps):
+        state = one_step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tot = torch.tensor([state[0], state[1], state[2]], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        g_ins, g_hit, g_size = (int(x) for x in tot.cpu())
+    else:
+        g_ins, g_hit, g_size = state[0], state[1], state[2]
+
+    # size-independent parity properties at full size (the oracle cannot run 1e8 keys in seconds):
+    # every distinct key inserted exactly once, every query found
+    assert g_ins == args.keys * world, (g_ins, args.keys * world)
+    assert g_hit == args.queries * world, (g_hit, args.queries * world)
+    assert g_size == args.keys * world
+
+    if rank == 0:
+        ops_per_step = (args.keys + args.queries) * world
+        ms_per_step = elapsed / args.steps * 1e3
+        ins_rate = args.keys * world / (np.mean(ins_ms) * 1e-3)
+        find_rate = args.queries * world / (np.mean(find_ms) * 1e-3)
+        # dominant kernel of the insert path, timed with HIP events inside the library on the table's stream
+        dom = max((k for k in prof if k.startswith("k_")), key=lambda k: prof[k][1] / max(prof[k][0], 1) * (prof[k][0] / args.steps))
+        launches, total_ms = prof[dom]
+        per_launch_ms = total_ms / launches
+        units = {"k_find": args.queries, "k_count": args.queries}.get(dom, args.keys)
+        bpu = {"k_find": B_FIND_HIT}.get(dom, B_INSERT_NEW)
+        launches_per_step = launches / args.steps
+        alg_bytes = units * bpu / max(launches_per_step, 1.0)          # algorithmic bytes one launch accounts for
+        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "kmer_inserts_plus_finds_per_sec",
+            "value": ops_per_step / (elapsed / args.steps),
+            "unit": "kmer_ops/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[1]: Robin Hood table, %d distinct random 64-bit k-mers per GPU (max load 0.8 -> "
+                                   "capacity %d, load %.3f), murmur3avx64 seed 43, then %d all-hit finds per GPU%s"
+                                   % (args.keys, state[3], state[2] / state[3], args.queries,
+                                      "; keys sharded by murmur3(seed 9876543) over RCCL all_to_all" if distributed else ""),
+                       "keys_per_gpu": args.keys, "queries_per_gpu": args.queries, "table": "hashmap_robinhood_doubling",
+                       "hash": "murmur3avx64", "max_load_factor": 0.8, "min_load_factor": 0.35},
+            "inserts_per_s": ins_rate, "finds_per_s": find_rate,
+            "insert_ms": float(np.mean(ins_ms)), "find_ms": float(np.mean(find_ms)),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms,
+                         "whole_insert_path_frac": ins_rate / world * B_INSERT_NEW / 1e9 / HBM_PEAK_GBS,
+                         "whole_find_path_frac": find_rate / world * B_FIND_HIT / 1e9 / HBM_PEAK_GBS},
+            "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
+        }
+        if not args.no_cpu_baseline and not distributed:
+            out["cpu_baseline"] = cpu_baseline(keys, vals, q)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

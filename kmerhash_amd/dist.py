@@ -1,0 +1,166 @@
+"""Key-space sharding of the table across the GPUs of one node (one process per GPU, torch.distributed).
+
+Replaces the reference's MPI layer for this path (dsc::batched_robinhood_map_base::insert_p / count_p /
+find_p / erase_p, distributed_batched_robinhood_map.hpp:910-1194,1258,1619,2169):
+    rank = DistHash(key, seed 9876543) & (p-1)   (or % p)            :513-534,652
+    permute the batch into p contiguous segments                      :632-741 (assign_count_permute)
+    all2all(counts) ; all2allv(payload)                               :1024,1126 -> RCCL all_to_all_single over xGMI
+    local batch op on the received keys                               :1158
+    queries: results travel back with the swapped counts              :1495
+Every GPU owns an independent local table whose storage hash uses a different seed (43), so local bucket
+bits are uncorrelated with the shard bits.  Receive order is fixed (source rank 0..p-1, then position), which
+makes first-value-wins across ranks deterministic and replayable by the CPU model in the tests.
+
+`backend` objects supply the two device-specific pieces so that the exchange logic can be exercised on CPU
+(gloo, world_size 2) with the oracle in tests; the product backend is GpuBackend.
+"""
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    torch = None
+    dist = None
+
+DIST_SEED = 9876543   # distributed_batched_robinhood_map.hpp:513-534
+
+
+class GpuBackend:
+    """local table = libkmerhash_amd table on this rank's GPU; sharding = kh_shard_permute (stable)"""
+
+    def __init__(self, device, kind="rh", capacity=128, min_lf=0.35, max_lf=0.8, hash="murmur3avx64", seed=43,
+                 dist_hash="murmur3avx64", dist_seed=DIST_SEED):
+        import ctypes as C
+        from . import _capi as K
+        from . import table as T
+        self.C, self.K = C, K
+        self.device = device
+        cls = T.hashmap_robinhood_doubling if kind == "rh" else T.hashmap_linearprobe_doubling
+        self.table = cls(capacity, min_lf, max_lf, hash=hash, seed=seed, device=device)
+        self.dist_hash = T._hash_id(dist_hash)
+        self.dist_seed = dist_seed
+        self.torch_device = torch.device("cuda", device)
+
+    def shard(self, keys, vals, p):
+        """-> (keys grouped by destination rank, vals grouped, counts[p]) ; stable inside a rank"""
+        n = keys.numel()
+        ok = torch.empty_like(keys)
+        ov = torch.empty_like(vals) if vals is not None else None
+        counts = (self.C.c_uint64 * p)()
+        st = self.K.lib().kh_shard_permute(self.dist_hash, self.dist_seed, p, keys.data_ptr(),
+                                           vals.data_ptr() if vals is not None else None, n, ok.data_ptr(),
+                                           ov.data_ptr() if ov is not None else None, counts, self.device,
+                                           torch.cuda.current_stream(self.device).cuda_stream)
+        if st != self.K.KH_OK:
+            raise self.K.KhError(st, "kh_shard_permute")
+        return ok, ov, [int(c) for c in counts]
+
+    def empty(self, n, dtype):
+        return torch.empty(n, dtype=dtype, device=self.torch_device)
+
+
+class ShardedTable:
+    """dsc::batched_robinhood_map-style distributed map over torch.distributed (RCCL when backend='nccl')."""
+
+    def __init__(self, backend, group=None):
+        self.b = backend
+        self.group = group
+        self.p = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
+
+    @property
+    def local(self):
+        return self.b.table
+
+    # ---- exchange helpers ---------------------------------------------------------------------------
+    def _exchange_counts(self, send_counts):
+        if self.p == 1:
+            return list(send_counts)
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.b.torch_device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.group)       # mxx::all2all(send_counts) :1024
+        return [int(x) for x in rc.cpu()]
+
+    def _a2av(self, send, send_counts, recv_counts):
+        if self.p == 1:
+            return send
+        out = self.b.empty(sum(recv_counts), send.dtype)
+        dist.all_to_all_single(out, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                               group=self.group)               # khmxx::distribute_permuted (mxx::all2allv) :1126
+        return out
+
+    def _route(self, keys, vals=None):
+        ok, ov, sc = self.b.shard(keys, vals, self.p)
+        rc = self._exchange_counts(sc)
+        rk = self._a2av(ok, sc, rc)
+        rv = self._a2av(ov, sc, rc) if ov is not None else None
+        return rk, rv, sc, rc
+
+    # ---- batch operations (collective: every rank calls them) -----------------------------------------
+    def insert(self, keys, vals, chunks=1):
+        """insert_p :910-1194.  With chunks > 1 the batch is cut into `chunks` pieces and the exchange of
+        piece k+1 (comm stream) overlaps the local insert of piece k (compute stream) -- the RCCL analogue of
+        khmxx::ialltoallv_and_modify (incremental_mxx.hpp:3437-3645)."""
+        n = keys.numel()
+        if chunks <= 1 or self.p == 1 or not keys.is_cuda:
+            rk, rv, _, _ = self._route(keys, vals)
+            return self.local.insert(rk, rv)
+        comm = torch.cuda.Stream(device=self.b.torch_device)
+        cur = torch.cuda.current_stream(self.b.torch_device)
+        bounds = [n * i // chunks for i in range(chunks + 1)]
+        inserted = 0
+        pending = None
+        for i in range(chunks):
+            a, b = bounds[i], bounds[i + 1]
+            comm.wait_stream(cur)
+            with torch.cuda.stream(comm):
+                rk, rv, _, _ = self._route(keys[a:b], vals[a:b])
+                rk.record_stream(cur)
+                rv.record_stream(cur)
+                ev = torch.cuda.Event()
+                ev.record(comm)
+            if pending is not None:
+                pk, pv, pev = pending
+                cur.wait_event(pev)
+                inserted += self.local.insert(pk, pv)
+            pending = (rk, rv, ev)
+        pk, pv, pev = pending
+        cur.wait_event(pev)
+        inserted += self.local.insert(pk, pv)
+        return inserted
+
+    def count(self, keys):
+        """count_p :1258: results come back in the PERMUTED input order (grouped by owner rank), like the
+        reference, together with the permuted keys."""
+        ok, _, sc = self.b.shard(keys, None, self.p)
+        rc = self._exchange_counts(sc)
+        rk = self._a2av(ok, sc, rc)
+        res = self.local.count(rk)
+        back = self._a2av(res, rc, sc)     # swapped counts :1495
+        return ok, back
+
+    def find(self, keys):
+        """find_p :1619: (permuted keys, values, found flags) aligned with the permuted keys"""
+        ok, _, sc = self.b.shard(keys, None, self.p)
+        rc = self._exchange_counts(sc)
+        rk = self._a2av(ok, sc, rc)
+        vals, found = self.local.find_values(rk)
+        return ok, self._a2av(vals, rc, sc), self._a2av(found, rc, sc)
+
+    def erase(self, keys):
+        """erase_p :2169: returns the number erased on this rank's local table"""
+        rk, _, _, _ = self._route(keys, None)
+        return self.local.erase(rk)
+
+    def size(self):
+        """global size = sum of local sizes"""
+        n = self.local.size()
+        if self.p == 1:
+            return n
+        t = torch.tensor([n], dtype=torch.int64, device=self.b.torch_device)
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def local_size(self):
+        return self.local.size()
