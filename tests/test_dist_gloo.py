@@ -1,0 +1,143 @@
+"""CPU: the N>1 path (shard -> all_to_all counts -> all_to_allv payload -> local op -> results back with the
+swapped counts) on world_size 2 over gloo.  The device-specific pieces (local table, shard permute) are
+supplied by an oracle-backed test backend; the exchange logic under test is kmerhash_amd.dist.ShardedTable,
+the same code the GPU ranks run over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleBackend:
+    def __init__(self, O, kind):
+        self.O = O
+        self.torch_device = torch.device("cpu")
+
+        class T:
+            def __init__(s):
+                s.t = O.OracleTable(kind, 128, 0.35, 0.8, O.HASH_MURMUR3_X86, 43)
+
+            def insert(s, k, v):
+                return s.t.insert(k.numpy().view(np.uint64), v.numpy().view(np.uint32))
+
+            def count(s, k):
+                return torch.from_numpy(s.t.count(k.numpy().view(np.uint64)))
+
+            def find_values(s, k):
+                v, f = s.t.find(k.numpy().view(np.uint64))
+                return torch.from_numpy(v.view(np.int32)), torch.from_numpy(f)
+
+            def erase(s, k):
+                return s.t.erase(k.numpy().view(np.uint64))
+
+            def size(s):
+                return s.t.size()
+        self.table = T()
+
+    def shard(self, keys, vals, p):
+        from kmerhash_amd.dist import DIST_SEED
+        k = keys.numpy().view(np.uint64)
+        r = (self.O.hash_batch(self.O.HASH_MURMUR3_X86, DIST_SEED, k) % np.uint64(p)).astype(np.int64)
+        order = np.argsort(r, kind="stable")
+        counts = np.bincount(r, minlength=p).tolist()
+        ok = torch.from_numpy(k[order].view(np.int64).copy())
+        ov = torch.from_numpy(vals.numpy()[order].copy()) if vals is not None else None
+        return ok, ov, counts
+
+    def empty(self, n, dtype):
+        return torch.empty(n, dtype=dtype)
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle_py as O
+        from kmerhash_amd import workloads as W
+        from kmerhash_amd.dist import ShardedTable, DIST_SEED
+        n = 30_000
+        # every rank generates its own stream (BenchmarkDistHashTables.cpp:908-936), with cross-rank duplicates
+        keys, vals = W.w1_benchmark_hashtables(n, seed=100)          # same key universe on both ranks
+        p = W.shuffle_perm(n, 7 + rank)
+        keys, vals = keys[p], (vals[p] + np.uint32(rank * 1_000_000))
+        st = ShardedTable(OracleBackend(O, O.KIND_RH))
+        tk = torch.from_numpy(keys.view(np.int64).copy())
+        tv = torch.from_numpy(vals.view(np.int32).copy())
+        st.insert(tk, tv)
+        # single-table model: receive order is (source rank 0..p-1, then position)
+        allk = [None] * world
+        allv = [None] * world
+        dist.all_gather_object(allk, keys)
+        dist.all_gather_object(allv, vals)
+        owner = lambda k: (O.hash_batch(O.HASH_MURMUR3_X86, DIST_SEED, k) % np.uint64(world)).astype(np.int64)
+        model = O.OracleTable(O.KIND_RH, 128, 0.35, 0.8, O.HASH_MURMUR3_X86, 43)
+        for r in range(world):
+            m = owner(allk[r]) == rank
+            model.insert(allk[r][m], allv[r][m])
+        loc = st.local.t
+        assert loc.size() == model.size() and loc.capacity() == model.capacity()
+        assert np.array_equal(loc.export_info(), model.export_info())
+        a, b = loc.sorted_items(), model.sorted_items()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        gsize = st.size()
+        assert gsize == len(np.unique(np.concatenate(allk)))
+        # queries: results come back aligned with the permuted keys
+        qk = np.concatenate([keys[:5000], W.distinct_u64(5000, seed=55 + rank)])
+        pk, cnt = st.count(torch.from_numpy(qk.view(np.int64).copy()))
+        universe = set(np.concatenate(allk).tolist())
+        exp = np.array([1 if int(k) in universe else 0 for k in pk.numpy().view(np.uint64)], dtype=np.uint8)
+        assert np.array_equal(cnt.numpy(), exp)
+        pk2, fv, ff = st.find(torch.from_numpy(qk.view(np.int64).copy()))
+        assert np.array_equal(ff.numpy(), exp)
+        # first-wins across ranks: the value of a duplicated key is the one from the lowest source rank
+        first = {}
+        for r in range(world):
+            for k, v in zip(allk[r].tolist(), allv[r].tolist()):
+                first.setdefault(k, v)
+        pkk = pk2.numpy().view(np.uint64)
+        got = fv.numpy().view(np.uint32)
+        for i in np.nonzero(exp)[0][:2000]:
+            assert got[i] == first[int(pkk[i])]
+        ne = st.erase(torch.from_numpy(keys[:1000].view(np.int64).copy()))
+        tot = torch.tensor([ne])
+        dist.all_reduce(tot)
+        both = np.unique(np.concatenate([a[:1000] for a in allk]))
+        assert int(tot.item()) == len(both)
+        assert st.size() == gsize - len(both)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_table_world2_gloo(oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
