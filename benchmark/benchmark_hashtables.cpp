@@ -1,0 +1,114 @@
+// benchmark_hashtables.cpp -- our own driver for the reference's primary single-process benchmark
+// (reference benchmark/BenchmarkHashTables.cpp: main :1591, benchmark_hashmap<MAP> :1037-1186), written against
+// the drop-in headers.  It keeps the phase sequence and the run-time flags that matter for this path:
+//
+//     -m robinhood|linearprobe   map type                 (:1399-1409; the GPU tables of this repo)
+//     -N <count>                 input pairs, default 100M (:1441)
+//     -Q <query_frac>            queries = N / Q, default 10 (README.md:84 run; the source default is 2)
+//     -R <repeat_rate>           multiplicity 1..R per key, default 10 (mean 5.5)   (:192-223)
+//     --max_load / --min_load    load factors, default 0.8 / 0.35                    (:1053-1056)
+//     -r <repeats>               timed repeats of the whole sequence (fresh map each), default 1
+//
+// Phases, each timed on the host clock around the batch call (host vectors in, host vectors out -- the
+// reference's semantics, so the numbers INCLUDE PCIe transfers): insert, find, count, erase, count2.
+// Input generation uses splitmix64 instead of glibc rand()/random_shuffle (portable streams).
+// The kmerind pieces of the reference driver (TCLAP, BL_BENCH, mxx, Kmer) are not used.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kmerhash/hashmap_robinhood.hpp"
+#include "kmerhash/hashmap_linearprobe.hpp"
+
+namespace {
+
+struct SplitMix { uint64_t s; uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); } };
+
+typedef std::pair<uint64_t, uint32_t> pair_t;
+
+// generate_input (:182-227): key = 62-bit draw (31-mer sanitize); emit (key,i) then draw%repeats more copies; shuffle
+std::vector<pair_t> generate_input(size_t count, size_t repeats) {
+  std::vector<pair_t> out;
+  out.reserve(count);
+  SplitMix g{23};
+  for (size_t i = 0; i < count;) {
+    uint64_t k = g.next() & ((uint64_t(1) << 62) - 1);
+    out.push_back(pair_t(k, uint32_t(i))); ++i;
+    size_t freq = g.next() % repeats;
+    for (size_t j = 0; j < freq && i < count; ++j, ++i) out.push_back(pair_t(k, uint32_t(i)));
+  }
+  SplitMix sh{29};
+  for (size_t i = out.size(); i > 1; --i) std::swap(out[i - 1], out[sh.next() % i]);   // Fisher-Yates
+  return out;
+}
+
+struct Timer {
+  std::chrono::steady_clock::time_point t0;
+  void start() { t0 = std::chrono::steady_clock::now(); }
+  double stop() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// benchmark_hashmap<MAP> (:1037-1186): the map type arrives as a 5-parameter template-template
+template <template <typename, typename, typename, typename, typename> class MAP>
+void benchmark_hashmap(std::string const& name, std::vector<pair_t> const& input, size_t query_frac, float max_load, float min_load) {
+  using MAP_TYPE = MAP<uint64_t, uint32_t, ::fsc::hash::murmur3avx64<uint64_t>, ::std::equal_to<uint64_t>, ::std::allocator<pair_t> >;
+  Timer tm;
+  MAP_TYPE map;
+  map.set_max_load_factor(max_load);
+  map.set_min_load_factor(min_load);
+  std::vector<uint64_t> query;
+  query.reserve(input.size() / query_frac);
+  for (size_t i = 0; i < input.size() / query_frac; ++i) query.push_back(input[i].first);
+
+  tm.start(); map.insert(input); double t_ins = tm.stop();
+  size_t sz = map.size();
+  tm.start(); auto found = map.find(query.begin(), query.end()); double t_find = tm.stop();
+  tm.start(); auto counts = map.count(query.begin(), query.end()); double t_count = tm.stop();
+  size_t present = 0; for (auto c : counts) present += c;
+  tm.start(); size_t erased = map.erase(query.begin(), query.end()); double t_erase = tm.stop();
+  tm.start(); auto counts2 = map.count(query.begin(), query.end()); double t_count2 = tm.stop();
+  size_t present2 = 0; for (auto c : counts2) present2 += c;
+
+  std::printf("[%s] N=%zu distinct=%zu capacity=%zu queries=%zu\n", name.c_str(), input.size(), sz, size_t(map.capacity()), query.size());
+  std::printf("  insert  %9.4f s  %10.3f M/s\n", t_ins, input.size() / t_ins / 1e6);
+  std::printf("  find    %9.4f s  %10.3f M/s  (found %zu)\n", t_find, query.size() / t_find / 1e6, found.size());
+  std::printf("  count   %9.4f s  %10.3f M/s  (present %zu)\n", t_count, query.size() / t_count / 1e6, present);
+  std::printf("  erase   %9.4f s  %10.3f M/s  (erased %zu)\n", t_erase, query.size() / t_erase / 1e6, erased);
+  std::printf("  count2  %9.4f s  %10.3f M/s  (present %zu)\n", t_count2, query.size() / t_count2 / 1e6, present2);
+  if (found.size() != query.size() || present != query.size() || present2 != 0 || map.size() != sz - erased) {
+    std::printf("  SELF-CHECK FAILED\n");
+    std::exit(2);
+  }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string map = "robinhood";
+  size_t N = 100000000, Q = 10, R = 10, reps = 1;
+  float max_load = 0.8f, min_load = 0.35f;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto need = [&](const char* f) { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", f); std::exit(1); } return argv[++i]; };
+    if (a == "-m") map = need("-m");
+    else if (a == "-N") N = std::strtoull(need("-N"), nullptr, 10);
+    else if (a == "-Q") Q = std::strtoull(need("-Q"), nullptr, 10);
+    else if (a == "-R") R = std::strtoull(need("-R"), nullptr, 10);
+    else if (a == "-r") reps = std::strtoull(need("-r"), nullptr, 10);
+    else if (a == "--max_load") max_load = std::strtof(need("--max_load"), nullptr);
+    else if (a == "--min_load") min_load = std::strtof(need("--min_load"), nullptr);
+    else { std::fprintf(stderr, "usage: %s [-m robinhood|linearprobe] [-N n] [-Q query_frac] [-R repeat_rate] [-r repeats] [--max_load f] [--min_load f]\n", argv[0]); return 1; }
+  }
+  if (Q == 0 || R == 0) return 1;
+  std::vector<pair_t> input = generate_input(N, R);
+  for (size_t r = 0; r < reps; ++r) {
+    if (map == "robinhood") benchmark_hashmap<::fsc::hashmap_robinhood_doubling>("robinhood", input, Q, max_load, min_load);
+    else if (map == "linearprobe") benchmark_hashmap<::fsc::hashmap_linearprobe_doubling>("linearprobe", input, Q, max_load, min_load);
+    else { std::fprintf(stderr, "unknown map %s\n", map.c_str()); return 1; }
+  }
+  return 0;
+}

@@ -6,7 +6,7 @@
  *     fsc::hashmap_linearprobe_doubling (reference include/kmerhash/hashmap_linearprobe.hpp:96-98)
  * for 64-bit keys (2-bit packed k-mers, k <= 32) with 32-bit mapped values, and of the 64-bit hash
  * functors they are instantiated with.  Plain pointers and sizes only; no C++/torch types cross it.
- * The C++ template shim (include/kmerhash_amd/*.hpp) and the Python host layer (kmerhash_amd/) are
+ * The C++ template shim (include/kmerhash_amd/hashmap.hpp) and the Python host layer (kmerhash_amd/) are
  * thin callers of exactly these entry points; INTEGRATION.md shows the reference-side binding.
  *
  * Every function returns a kh_status; kh_last_error() gives the text of the last failure on a table.
@@ -129,6 +129,9 @@ kh_status kh_profile_reset(kh_table* t);
 kh_status kh_profile_query(kh_table* t, const char* prefix, double* total_ms, uint64_t* launches);
 /* writes up to `cap` bytes of "name launches total_ms\n" lines */
 kh_status kh_profile_dump(kh_table* t, char* buf, uint64_t cap);
+
+/* freed table buffers and workspaces are cached per device for reuse; this returns them to the driver */
+kh_status kh_release_cached_memory(int device);
 
 const char* kh_version(void);
 

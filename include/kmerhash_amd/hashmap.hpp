@@ -1,0 +1,439 @@
+// kmerhash_amd/hashmap.hpp -- C++11 template shim: the reference's table API over the C-ABI.
+//
+// Provides, with the reference's own names, template parameters and member set,
+//     fsc::hashmap_robinhood_doubling <Key, T, Hash, Equal, Allocator>   (reference hashmap_robinhood.hpp:124-126)
+//     fsc::hashmap_linearprobe_doubling<Key, T, Hash, Equal, Allocator>  (reference hashmap_linearprobe.hpp:96-98)
+//     fsc::hash::{identity, murmur, murmur_x86, murmur3avx64, farm}<T>   (hash_new.hpp:135-328, murmurhash3_64_avx.hpp:1553)
+// so that a caller written against kmerhash (e.g. benchmark_hashmap<MAP>, BenchmarkHashTables.cpp:1037-1186, which
+// takes the map as a 5-parameter template-template) compiles against this header and links libkmerhash_amd.so.
+// Every member forwards to exactly one kh_* entry point of include/kmerhash_amd.h; there is no host
+// implementation of the table here and no CPU fallback: unsupported instantiations fail at compile time.
+//
+// Supported instantiation (everything the reference's benchmarks use on this path):
+//     sizeof(Key) == 8, trivially copyable (uint64_t, bliss::common::Kmer<31,DNA,uint64_t>, ...)
+//     sizeof(T)   == 4, trivially copyable (uint32_t, int, float)
+//     Hash  = one of the fsc::hash functors below, or std::hash<Key> for an integral Key (identity in libstdc++)
+//     Equal = std::equal_to<Key> (bitwise equality of the 8 key bytes)
+//
+// Differences a caller can observe (DESIGN.md "Boundary"):
+//   * iterators are read-only views of a host snapshot taken by begin()/find(); slot order is the table's
+//     canonical home-bucket order, not the reference's insertion-history order (both are unspecified orders);
+//   * a Robin Hood probe distance that would reach 128 raises std::runtime_error and leaves the table
+//     unchanged (the reference asserts, or silently corrupts under -DNDEBUG, hashmap_robinhood.hpp:556).
+#ifndef KMERHASH_AMD_HASHMAP_HPP_
+#define KMERHASH_AMD_HASHMAP_HPP_
+
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <iostream>
+#include <iterator>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../kmerhash_amd.h"
+
+namespace kmerhash_amd {
+namespace detail {
+
+// scalar host evaluation of the same hashes the kernels use (kmerhash_amd/csrc/kh_hash.h restated for the host
+// shim so that this header only depends on the C-ABI header)
+inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t rotr64(uint64_t x, int r) { return (x >> r) | (x << (64 - r)); }
+inline uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+inline uint64_t fmix64(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k; }
+inline uint64_t murmur3_x86_128_lo64(uint64_t key, uint32_t seed) {
+  const uint32_t c1 = 0x239b961bu, c2 = 0xab0e9789u, c3 = 0x38b34ae5u;
+  uint32_t h1 = seed, h2 = seed, h3 = seed, h4 = seed, k1 = uint32_t(key), k2 = uint32_t(key >> 32);
+  k2 *= c2; k2 = rotl32(k2, 16); k2 *= c3; h2 ^= k2;
+  k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2; h1 ^= k1;
+  h1 ^= 8u; h2 ^= 8u; h3 ^= 8u; h4 ^= 8u;
+  h1 += h2; h1 += h3; h1 += h4; h2 += h1; h3 += h1; h4 += h1;
+  h1 = fmix32(h1); h2 = fmix32(h2); h3 = fmix32(h3); h4 = fmix32(h4);
+  h1 += h2; h1 += h3; h1 += h4; h2 += h1;
+  return uint64_t(h1) | (uint64_t(h2) << 32);
+}
+inline uint64_t murmur3_x64_128_h0(uint64_t key, uint32_t seed) {
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = seed, h2 = seed, k1 = key;
+  k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+  h1 ^= 8u; h2 ^= 8u; h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  return h1 + h2;
+}
+inline uint64_t farm_len16(uint64_t u, uint64_t v, uint64_t mul) {
+  uint64_t a = (u ^ v) * mul; a ^= (a >> 47);
+  uint64_t b = (v ^ a) * mul; b ^= (b >> 47);
+  return b * mul;
+}
+inline uint64_t farm64_seed(uint64_t key, uint64_t seed) {
+  const uint64_t k2 = 0x9ae16a3b2f90404fULL, mul = k2 + 16;
+  uint64_t a = key + k2, b = key;
+  uint64_t c = rotr64(b, 37) * mul + a, d = (rotr64(a, 25) + b) * mul;
+  return farm_len16(farm_len16(c, d, mul) - k2, seed, 0x9ddfea08eb382d69ULL);
+}
+template <typename K> inline uint64_t key_bits(K const& k) {
+  static_assert(sizeof(K) == 8, "kmerhash_amd: keys must be 8 bytes (one packed 64-bit k-mer word)");
+  uint64_t b; std::memcpy(&b, &k, 8); return b;
+}
+
+}  // namespace detail
+
+// maps a hash functor type to the kh_hash id the device kernels implement
+template <typename Hash, typename Key, typename Enable = void>
+struct hash_traits { static constexpr bool supported = false; };
+
+}  // namespace kmerhash_amd
+
+namespace fsc {
+namespace hash {
+
+#define KMERHASH_AMD_HASH_FUNCTOR(NAME, ID, SEED_T, EXPR)                                         \
+  template <typename T> class NAME {                                                               \
+   protected:                                                                                      \
+    SEED_T seed;                                                                                   \
+   public:                                                                                         \
+    static constexpr size_t batch_size = 1;                                                        \
+    static constexpr kh_hash kh_id = ID;                                                           \
+    using result_type = uint64_t;                                                                  \
+    using argument_type = T;                                                                       \
+    NAME(SEED_T const& _seed = 43) : seed(_seed) {}                                                \
+    uint64_t kh_seed() const { return uint64_t(seed); }                                            \
+    inline uint64_t operator()(const T& key) const {                                               \
+      const uint64_t k = ::kmerhash_amd::detail::key_bits(key); (void)k;                           \
+      return EXPR;                                                                                 \
+    }                                                                                              \
+  };                                                                                               \
+  template <typename T> constexpr size_t NAME<T>::batch_size;                                      \
+  template <typename T> constexpr kh_hash NAME<T>::kh_id;
+
+// hash_new.hpp:135-166
+KMERHASH_AMD_HASH_FUNCTOR(identity, KH_HASH_IDENTITY, uint32_t, k)
+// hash_new.hpp:206-235 (MurmurHash3_x64_128, h[0])
+KMERHASH_AMD_HASH_FUNCTOR(murmur, KH_HASH_MURMUR3_X64_128_H0, uint32_t, ::kmerhash_amd::detail::murmur3_x64_128_h0(k, seed))
+// hash_new.hpp:218-233 (MurmurHash3_x86_128, low 64 bits)
+KMERHASH_AMD_HASH_FUNCTOR(murmur_x86, KH_HASH_MURMUR3_X86_128_LO64, uint64_t, ::kmerhash_amd::detail::murmur3_x86_128_lo64(k, uint32_t(seed)))
+// murmurhash3_64_avx.hpp:1553-1651 (same function, AVX2 batch form in the reference)
+KMERHASH_AMD_HASH_FUNCTOR(murmur3avx64, KH_HASH_MURMUR3_X86_128_LO64, uint32_t, ::kmerhash_amd::detail::murmur3_x86_128_lo64(k, seed))
+// hash_new.hpp:309-328 (util::Hash64WithSeed; parity unpinned)
+KMERHASH_AMD_HASH_FUNCTOR(farm, KH_HASH_FARM64, uint64_t, ::kmerhash_amd::detail::farm64_seed(k, seed))
+#undef KMERHASH_AMD_HASH_FUNCTOR
+
+}  // namespace hash
+}  // namespace fsc
+
+namespace kmerhash_amd {
+
+template <typename Hash, typename Key>
+struct hash_traits<Hash, Key, typename std::enable_if<(Hash::kh_id >= 0)>::type> {
+  static constexpr bool supported = true;
+  static kh_hash id(Hash const&) { return Hash::kh_id; }
+  static uint64_t seed(Hash const& h) { return h.kh_seed(); }
+};
+// std::hash of a 64-bit integral key is the identity in libstdc++ (the reference's default Hash)
+template <typename Key>
+struct hash_traits<std::hash<Key>, Key, typename std::enable_if<std::is_integral<Key>::value && sizeof(Key) == 8>::type> {
+  static constexpr bool supported = true;
+  static kh_hash id(std::hash<Key> const&) { return KH_HASH_IDENTITY; }
+  static uint64_t seed(std::hash<Key> const&) { return 0; }
+};
+
+namespace detail {
+
+template <kh_kind KIND, typename Key, typename T, typename Hash, typename Equal, typename Allocator>
+class gpu_hashmap {
+  static_assert(sizeof(Key) == 8 && std::is_trivially_copyable<Key>::value,
+                "kmerhash_amd: Key must be an 8-byte trivially copyable type (64-bit packed k-mer)");
+  static_assert(sizeof(T) == 4 && std::is_trivially_copyable<T>::value,
+                "kmerhash_amd: mapped type must be a 4-byte trivially copyable type");
+  static_assert(hash_traits<Hash, Key>::supported,
+                "kmerhash_amd: Hash must be one of fsc::hash::{identity,murmur,murmur_x86,murmur3avx64,farm} or std::hash of a 64-bit integer");
+  static_assert(std::is_same<Equal, std::equal_to<Key> >::value, "kmerhash_amd: Equal must be std::equal_to<Key>");
+  static_assert(sizeof(std::pair<Key, T>) == 16, "kmerhash_amd: std::pair<Key,T> must be 16 bytes (key @0, value @8)");
+
+ public:
+  using key_type = Key;
+  using mapped_type = T;
+  using value_type = std::pair<Key, T>;
+  using hasher = Hash;
+  using key_equal = Equal;
+  using allocator_type = Allocator;
+  using size_type = size_t;
+  using difference_type = ptrdiff_t;
+  using reference = value_type&;
+  using const_reference = value_type const&;
+  using pointer = value_type*;
+  using const_pointer = value_type const*;
+
+  // forward iterator over a host snapshot of the occupied slots
+  class const_iterator {
+   public:
+    using iterator_category = std::forward_iterator_tag;
+    using value_type = std::pair<Key, T>;
+    using difference_type = ptrdiff_t;
+    using pointer = value_type const*;
+    using reference = value_type const&;
+    const_iterator() : pos(0) {}
+    const_iterator(std::shared_ptr<std::vector<value_type> > s, size_t p) : snap(std::move(s)), pos(p) {}
+    reference operator*() const { return (*snap)[pos]; }
+    pointer operator->() const { return &(*snap)[pos]; }
+    const_iterator& operator++() { ++pos; return *this; }
+    const_iterator operator++(int) { const_iterator t(*this); ++pos; return t; }
+    bool at_end() const { return !snap || pos >= snap->size(); }
+    bool operator==(const_iterator const& o) const {
+      if (at_end() || o.at_end()) return at_end() && o.at_end();
+      return snap == o.snap && pos == o.pos;
+    }
+    bool operator!=(const_iterator const& o) const { return !(*this == o); }
+   private:
+    std::shared_ptr<std::vector<value_type> > snap;
+    size_t pos;
+  };
+  using iterator = const_iterator;
+
+ protected:
+  kh_table* h_;
+  hasher hash;
+  key_equal eq;
+  mutable std::shared_ptr<std::vector<value_type> > snapshot_;
+
+  void check(kh_status s) const {
+    if (s == KH_OK) return;
+    std::string msg = h_ ? kh_last_error(h_) : "no table";
+    if (s == KH_ERR_FULL) throw std::logic_error(msg);   // hashmap_linearprobe.hpp:408,503
+    throw std::runtime_error("kmerhash_amd: status " + std::to_string(int(s)) + ": " + msg);
+  }
+  void create(size_t cap, float mn, float mx) {
+    h_ = nullptr;
+    kh_status s = kh_create(&h_, KIND, 8, 4, hash_traits<Hash, Key>::id(hash), hash_traits<Hash, Key>::seed(hash), cap, mn, mx, 0);
+    if (s != KH_OK) throw std::runtime_error("kmerhash_amd: kh_create failed with status " + std::to_string(int(s)) +
+                                             " (no usable MI355X / HIP runtime?); there is no CPU fallback");
+  }
+  void touch() { snapshot_.reset(); }
+
+  // contiguous array of keys from an iterator range over keys or over (key,value) pairs
+  template <typename Iter>
+  static typename std::enable_if<std::is_constructible<Key, typename std::iterator_traits<Iter>::value_type>::value, std::vector<uint64_t> >::type
+  gather_keys(Iter b, Iter e) {
+    std::vector<uint64_t> k;
+    k.reserve(std::distance(b, e));
+    for (; b != e; ++b) { Key kk(*b); k.push_back(key_bits(kk)); }
+    return k;
+  }
+  template <typename Iter>
+  static typename std::enable_if<!std::is_constructible<Key, typename std::iterator_traits<Iter>::value_type>::value, std::vector<uint64_t> >::type
+  gather_keys(Iter b, Iter e) {
+    std::vector<uint64_t> k;
+    k.reserve(std::distance(b, e));
+    for (; b != e; ++b) k.push_back(key_bits((*b).first));
+    return k;
+  }
+
+ public:
+  gpu_hashmap(size_t cap, float mn, float mx) { create(cap, mn, mx); }
+  ~gpu_hashmap() { if (h_) kh_destroy(h_); }
+  gpu_hashmap(gpu_hashmap const&) = delete;
+  gpu_hashmap& operator=(gpu_hashmap const&) = delete;
+  gpu_hashmap(gpu_hashmap&& o) : h_(o.h_), hash(o.hash), eq(o.eq), snapshot_(std::move(o.snapshot_)) { o.h_ = nullptr; }
+
+  kh_table* native_handle() { return h_; }
+
+  // ---- load factors / sizes (hashmap_robinhood.hpp:261-289,406-416) ----
+  void set_min_load_factor(float const& f) { check(kh_set_min_load_factor(h_, f)); }
+  void set_max_load_factor(float const& f) { check(kh_set_max_load_factor(h_, f)); }
+  float get_load_factor() { float c; check(kh_get_load_factors(h_, nullptr, nullptr, &c)); return c; }
+  float get_min_load_factor() { float c; check(kh_get_load_factors(h_, &c, nullptr, nullptr)); return c; }
+  float get_max_load_factor() { float c; check(kh_get_load_factors(h_, nullptr, &c, nullptr)); return c; }
+  size_t size() const { uint64_t n; check(kh_size(h_, &n)); return n; }
+  void clear() { touch(); check(kh_clear(h_)); }
+  void reserve(size_type n) { touch(); check(kh_reserve(h_, n)); }
+  void rehash(size_type const& b) { touch(); check(kh_rehash(h_, b)); }
+
+  // ---- iteration (:295-309,388-403) ----
+  std::vector<std::pair<key_type, mapped_type> > to_vector() const {
+    std::vector<value_type> out;
+    uint64_t n = size(), m = 0;
+    std::vector<uint64_t> k(n ? n : 1);
+    std::vector<uint32_t> v(n ? n : 1);
+    check(kh_to_vector(h_, k.data(), v.data(), &m));
+    out.resize(m);
+    for (uint64_t i = 0; i < m; ++i) { std::memcpy(static_cast<void*>(&out[i].first), &k[i], 8); std::memcpy(static_cast<void*>(&out[i].second), &v[i], 4); }
+    return out;
+  }
+  std::vector<key_type> keys() const {
+    std::vector<value_type> all = to_vector();
+    std::vector<key_type> out(all.size());
+    for (size_t i = 0; i < all.size(); ++i) out[i] = all[i].first;
+    return out;
+  }
+  const_iterator cbegin() const {
+    if (!snapshot_) snapshot_ = std::make_shared<std::vector<value_type> >(to_vector());
+    return const_iterator(snapshot_, 0);
+  }
+  const_iterator cend() const { return const_iterator(); }
+  iterator begin() { return cbegin(); }
+  iterator end() { return cend(); }
+  void print() const {
+    uint64_t c; kh_capacity(h_, &c);
+    std::cout << "lsize " << size() << "\tbuckets " << c << std::endl;
+  }
+
+  // ---- insert (:522-717) ----
+  std::pair<iterator, bool> insert(value_type const& v) {
+    touch();
+    uint64_t n = 0;
+    check(kh_insert_pairs(h_, &v, 1, KH_MEM_HOST, &n));
+    return std::make_pair(find(v.first), n == 1);
+  }
+  std::pair<iterator, bool> insert(key_type const& key, mapped_type const& val) { return insert(value_type(key, val)); }
+  void insert(std::vector<value_type> const& input) {
+    touch();
+    uint64_t n = 0;
+    check(kh_insert_pairs(h_, input.data(), input.size(), KH_MEM_HOST, &n));
+  }
+  template <typename Iter, typename std::enable_if<std::is_constructible<value_type, typename std::iterator_traits<Iter>::value_type>::value, int>::type = 1>
+  void insert(Iter begin, Iter end) {
+    std::vector<value_type> tmp;
+    tmp.reserve(std::distance(begin, end));
+    for (; begin != end; ++begin) tmp.push_back(value_type(*begin));
+    insert(tmp);
+  }
+  // device-resident batches (keys u64[n], vals u32[n]); returns #inserted
+  size_type insert_device(const uint64_t* dkeys, const uint32_t* dvals, size_t n) {
+    touch();
+    uint64_t m = 0;
+    check(kh_insert(h_, dkeys, dvals, n, KH_MEM_DEVICE, &m));
+    return m;
+  }
+  // ---- update (:1274-1284) ----
+  iterator update(key_type const& k, mapped_type const& val) {
+    touch();
+    uint64_t kb = key_bits(k), n = 0;
+    uint32_t vb; std::memcpy(&vb, &val, 4);
+    check(kh_update(h_, &kb, &vb, 1, KH_MEM_HOST, &n));
+    return find(k);
+  }
+
+  // ---- count (:1102-1160) ----
+  size_type count(key_type const& k) const {
+    uint64_t kb = key_bits(k); uint8_t c = 0;
+    check(kh_count(h_, &kb, 1, KH_MEM_HOST, &c));
+    return c;
+  }
+  template <typename Iter>
+  std::vector<size_type> count(Iter begin, Iter end) {
+    std::vector<uint64_t> k = gather_keys(begin, end);
+    std::vector<uint8_t> c(k.size());
+    check(kh_count(h_, k.data(), k.size(), KH_MEM_HOST, c.data()));
+    return std::vector<size_type>(c.begin(), c.end());
+  }
+
+  // ---- find (:1165-1268) ----
+  iterator find(key_type const& k) {
+    uint64_t kb = key_bits(k), n = 0;
+    value_type out;
+    check(kh_find_compact_pairs(h_, &kb, 1, KH_MEM_HOST, &out, &n));
+    if (n == 0) return end();
+    return iterator(std::make_shared<std::vector<value_type> >(1, out), 0);
+  }
+  const_iterator find(key_type const& k) const { return const_cast<gpu_hashmap*>(this)->find(k); }
+  template <typename Iter>
+  std::vector<value_type> find(Iter begin, Iter end) {
+    std::vector<uint64_t> k = gather_keys(begin, end);
+    std::vector<value_type> out(k.size());
+    uint64_t n = 0;
+    check(kh_find_compact_pairs(h_, k.data(), k.size(), KH_MEM_HOST, out.data(), &n));
+    out.resize(n);
+    return out;
+  }
+
+  // ---- erase (:1294-1440) ----
+  template <typename Iter>
+  size_type erase_no_resize(Iter begin, Iter end) {
+    // the batch form of the reference differs from erase(Iter,Iter) only by the trailing resize check;
+    // thresholds are neutralised around the call so that no resize can trigger
+    float mn = get_min_load_factor();
+    set_min_load_factor(0.0f);
+    size_type r = erase(begin, end);
+    set_min_load_factor(mn);
+    return r;
+  }
+  size_type erase_no_resize(key_type const& k) { key_type a[1] = {k}; return erase_no_resize(a, a + 1); }
+  size_type erase(key_type const& k) {
+    touch();
+    uint64_t n = 0;
+    check(kh_erase_one(h_, key_bits(k), &n));
+    return n;
+  }
+  template <typename Iter>
+  size_type erase(Iter begin, Iter end) {
+    touch();
+    std::vector<uint64_t> k = gather_keys(begin, end);
+    uint64_t n = 0;
+    check(kh_erase(h_, k.data(), k.size(), KH_MEM_HOST, &n));
+    return n;
+  }
+};
+
+}  // namespace detail
+}  // namespace kmerhash_amd
+
+namespace fsc {
+
+template <typename Key, typename T, typename Hash = ::std::hash<Key>, typename Equal = ::std::equal_to<Key>,
+          typename Allocator = ::std::allocator<std::pair<Key, T> > >
+class hashmap_robinhood_doubling
+    : public ::kmerhash_amd::detail::gpu_hashmap<KH_KIND_ROBINHOOD, Key, T, Hash, Equal, Allocator> {
+  using base = ::kmerhash_amd::detail::gpu_hashmap<KH_KIND_ROBINHOOD, Key, T, Hash, Equal, Allocator>;
+
+ public:
+  using value_type = typename base::value_type;
+  // hashmap_robinhood.hpp:218-220
+  explicit hashmap_robinhood_doubling(size_t const& _capacity = 128, float const& _min_load_factor = 0.4,
+                                      float const& _max_load_factor = 0.9)
+      : base(_capacity, _min_load_factor, _max_load_factor) {}
+  // hashmap_robinhood.hpp:238-248
+  template <typename Iter, typename = typename std::enable_if<
+                               ::std::is_constructible<value_type, typename ::std::iterator_traits<Iter>::value_type>::value, int>::type>
+  hashmap_robinhood_doubling(Iter begin, Iter end, float const& _min_load_factor = 0.4, float const& _max_load_factor = 0.9)
+      : base(::std::distance(begin, end) / 4, _min_load_factor, _max_load_factor) {
+    this->insert(begin, end);
+  }
+  size_t capacity() { uint64_t c; this->check(kh_capacity(this->h_, &c)); return c; }   // :287
+  using base::insert;
+  // :721-836, :843, :1002: the same algorithm in the reference (insert_sort/_shuffled print a warning and call insert_integrated)
+  void insert_integrated(std::vector<value_type> const& input) { this->insert(input); }
+  template <typename LESS = ::std::less<Key> >
+  void insert_sort(::std::vector<value_type>& input) { this->insert(input); }
+  void insert_shuffled(::std::vector<value_type> const& input) { this->insert(input); }
+};
+
+template <typename Key, typename T, typename Hash = ::std::hash<Key>, typename Equal = ::std::equal_to<Key>,
+          typename Allocator = ::std::allocator<std::pair<Key, T> > >
+class hashmap_linearprobe_doubling
+    : public ::kmerhash_amd::detail::gpu_hashmap<KH_KIND_LINEARPROBE, Key, T, Hash, Equal, Allocator> {
+  using base = ::kmerhash_amd::detail::gpu_hashmap<KH_KIND_LINEARPROBE, Key, T, Hash, Equal, Allocator>;
+
+ public:
+  using value_type = typename base::value_type;
+  // hashmap_linearprobe.hpp:191-193
+  explicit hashmap_linearprobe_doubling(size_t const& _capacity = 128, float const& _min_load_factor = 0.2,
+                                        float const& _max_load_factor = 0.6)
+      : base(_capacity, _min_load_factor, _max_load_factor) {}
+  template <typename Iter, typename = typename std::enable_if<
+                               ::std::is_constructible<value_type, typename ::std::iterator_traits<Iter>::value_type>::value, int>::type>
+  hashmap_linearprobe_doubling(Iter begin, Iter end, float const& _min_load_factor = 0.2, float const& _max_load_factor = 0.6)
+      : base(::std::distance(begin, end) / 4, _min_load_factor, _max_load_factor) {
+    this->insert(begin, end);
+  }
+  // not part of the reference's public surface (buckets is protected there); kept for tests and drivers
+  size_t capacity() { uint64_t c; this->check(kh_capacity(this->h_, &c)); return c; }
+};
+
+}  // namespace fsc
+#endif  // KMERHASH_AMD_HASHMAP_HPP_

@@ -20,8 +20,8 @@
 #define KH_HS 4096u              // LDS de-dup set entries per workgroup (16 B each)
 #define KH_CHUNK_THREADS 512
 #define KH_PART_THREADS 512
-#define KH_PART_ITEMS 16
-#define KH_PART_TILE (KH_PART_THREADS * KH_PART_ITEMS)   // 8192 records per partition tile
+#define KH_PART_ITEMS 8
+#define KH_PART_TILE (KH_PART_THREADS * KH_PART_ITEMS)   // 4096 records per partition tile
 #define KH_NONE 0xFFFFFFFFFFFFFFFFull
 #define KH_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
@@ -169,17 +169,22 @@ __global__ void k_flag_tile_sums(const uint8_t* __restrict__ flags, uint64_t n, 
   if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// single-workgroup exclusive scan of u32 counts into u64 offsets (out has n+1 entries; out[n] = total)
+// single-workgroup exclusive scan of u32 counts into u64 offsets (out has n+1 entries; out[n] = total).
+// 1024 lanes x 16 consecutive items per sweep.
+#define KH_SCAN_ITEMS 16
 __global__ void k_scan_u32_to_u64(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
   __shared__ uint64_t wtot[16];
   __shared__ uint64_t carry_s;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (uint64_t base = 0; base < n; base += 1024) {
-    uint64_t i = base + tid;
-    uint64_t v = i < n ? in[i] : 0;
-    uint64_t incl = v;
+  for (uint64_t base = 0; base < n; base += 1024 * KH_SCAN_ITEMS) {
+    const uint64_t i0 = base + (uint64_t)tid * KH_SCAN_ITEMS;
+    uint32_t v[KH_SCAN_ITEMS];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < KH_SCAN_ITEMS; ++j) { v[j] = (i0 + j < n) ? in[i0 + j] : 0u; sum += v[j]; }
+    uint64_t incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
       uint64_t o = __shfl_up(incl, off, 64);
       if (lane >= (uint32_t)off) incl += o;
@@ -188,10 +193,12 @@ __global__ void k_scan_u32_to_u64(const uint32_t* __restrict__ in, uint64_t n, u
     __syncthreads();
     uint64_t wpre = 0;
     for (uint32_t w = 0; w < wid; ++w) wpre += wtot[w];
-    uint64_t carry = carry_s;
-    if (i < n) out[i] = carry + wpre + incl - v;
+    const uint64_t carry = carry_s;
+    uint64_t run = carry + wpre + incl - sum;
+#pragma unroll
+    for (int j = 0; j < KH_SCAN_ITEMS; ++j) { if (i0 + j < n) out[i0 + j] = run; run += v[j]; }
     __syncthreads();
-    if (tid == 1023) carry_s = carry + wpre + incl;
+    if (tid == 1023) carry_s = run;
     __syncthreads();
   }
   if (tid == 0) out[n] = carry_s;
@@ -315,45 +322,82 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_hist(KhPartParams P) {
     }
 }
 
+// One tile per workgroup.  Records are first counted per digit in LDS (rank = returning LDS atomic), the
+// tile's slice of every digit's output range is reserved with one global atomic per (tile, digit), then the
+// records are staged in LDS in digit order and streamed out, so that consecutive lanes write consecutive
+// addresses (a direct scatter costs 4.8x the algorithmic write traffic in partial-sector writes: profiles/
+// round-1 PMC notes).
 template <int HASH>
 __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P) {
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
+  __shared__ uint64_t lk[KH_PART_TILE];
+  __shared__ uint32_t lv[KH_PART_TILE];
+  __shared__ uint32_t li[KH_PART_TILE];
+  __shared__ uint16_t ld[KH_PART_TILE];
+  __shared__ uint32_t wtot[KH_PART_THREADS / 64];
   const uint32_t nb = P.nb;
-  uint32_t* hist = kh_dyn_smem;
-  unsigned long long* base = reinterpret_cast<unsigned long long*>(kh_dyn_smem + ((nb + 1u) & ~1u));
-  const uint32_t tid = threadIdx.x;
+  uint32_t* hist = kh_dyn_smem;                 // [nb] counts, then reused as running fill
+  uint32_t* loff = kh_dyn_smem + nb;            // [nb] exclusive offsets inside the tile
+  unsigned long long* gbase = reinterpret_cast<unsigned long long*>(kh_dyn_smem + 2 * ((nb + 1u) & ~1u));   // [nb]
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t ntiles = P.tiles ? *P.ntiles_dev : P.ntiles;
   if (blockIdx.x >= ntiles) return;
   KhTile d = kh_get_tile(P, blockIdx.x);
   for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) hist[i] = 0;
   __syncthreads();
   uint64_t key[KH_PART_ITEMS];
-  uint32_t dg[KH_PART_ITEMS], rk[KH_PART_ITEMS];
+  uint32_t val[KH_PART_ITEMS], idx[KH_PART_ITEMS], dg[KH_PART_ITEMS], rk[KH_PART_ITEMS];
 #pragma unroll
   for (int j = 0; j < KH_PART_ITEMS; ++j) {
     uint32_t i = tid + j * KH_PART_THREADS;
     if (i < d.len) {
       key[j] = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
+      val[j] = P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : 0u;
+      idx[j] = P.idx ? P.idx[d.beg + i] : (uint32_t)(d.beg + i);
       uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
       dg[j] = (q >> P.shift) & (nb - 1);
       rk[j] = atomicAdd(&hist[dg[j]], 1u);
     }
   }
   __syncthreads();
-  for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) {
-    uint32_t c = hist[i];
-    if (c) base[i] = atomicAdd(&P.cursor[(uint64_t)d.seg * nb + i], (unsigned long long)c);
+  // exclusive scan of the digit counts (each thread owns nb/512 consecutive bins) + global reservation
+  const uint32_t per = (nb + KH_PART_THREADS - 1) / KH_PART_THREADS;
+  uint32_t mine = 0;
+  for (uint32_t k = 0; k < per; ++k) { uint32_t b = tid * per + k; if (b < nb) mine += hist[b]; }
+  uint32_t incl = mine;
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t o = __shfl_up(incl, off, 64);
+    if (lane >= (uint32_t)off) incl += o;
+  }
+  if (lane == 63) wtot[wid] = incl;
+  __syncthreads();
+  uint32_t run = incl - mine;
+  for (uint32_t w = 0; w < wid; ++w) run += wtot[w];
+  for (uint32_t k = 0; k < per; ++k) {
+    uint32_t b = tid * per + k;
+    if (b < nb) {
+      uint32_t c = hist[b];
+      loff[b] = run;
+      run += c;
+      if (c) gbase[b] = atomicAdd(&P.cursor[(uint64_t)d.seg * nb + b], (unsigned long long)c);
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < KH_PART_ITEMS; ++j) {
     uint32_t i = tid + j * KH_PART_THREADS;
     if (i < d.len) {
-      uint64_t pos = base[dg[j]] + rk[j];
-      P.ok[pos] = key[j];
-      P.ov[pos] = P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : 0u;
-      P.oi[pos] = P.idx ? P.idx[d.beg + i] : (uint32_t)(d.beg + i);
+      uint32_t s = loff[dg[j]] + rk[j];
+      lk[s] = key[j]; lv[s] = val[j]; li[s] = idx[j]; ld[s] = (uint16_t)dg[j];
     }
+  }
+  __syncthreads();
+  for (uint32_t s = tid; s < d.len; s += KH_PART_THREADS) {
+    uint32_t dd = ld[s];
+    uint64_t pos = gbase[dd] + (s - loff[dd]);
+    P.ok[pos] = lk[s];
+    P.ov[pos] = lv[s];
+    P.oi[pos] = li[s];
   }
 }
 
@@ -647,6 +691,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_count(KhRebuildParam
 // K2b: one workgroup scans the chunk summaries.  x[c] = absolute first free position entering chunk c.
 // The table is circular: the run-over of the last chunk enters chunk 0, so the prefix composites are
 // applied to x0 = max(0, F_all(0) - cap) (a fixed point as long as one slot of the table stays free).
+#define KH_CARRY_ITEMS 8
 __global__ void k_chunk_carry(const long long* __restrict__ sumA, const long long* __restrict__ sumN, uint32_t nch, long long cap,
                               long long* __restrict__ xcarry, KhMP* __restrict__ prefix_tmp) {
   __shared__ KhMP s_wtot[16];
@@ -654,14 +699,25 @@ __global__ void k_chunk_carry(const long long* __restrict__ sumA, const long lon
   const uint32_t tid = threadIdx.x;
   if (tid == 0) { s_carry.A = KH_MP_NEG; s_carry.n = 0; }
   __syncthreads();
-  for (uint32_t base = 0; base < nch; base += 1024) {
-    uint32_t c = base + tid;
+  for (uint32_t base = 0; base < nch; base += 1024 * KH_CARRY_ITEMS) {
+    const uint32_t c0 = base + tid * KH_CARRY_ITEMS;
+    KhMP it[KH_CARRY_ITEMS];
     KhMP v; v.A = KH_MP_NEG; v.n = 0;
-    if (c < nch) { v.A = sumA[c]; v.n = sumN[c]; }
+#pragma unroll
+    for (int j = 0; j < KH_CARRY_ITEMS; ++j) {
+      it[j].A = KH_MP_NEG; it[j].n = 0;
+      if (c0 + j < nch) { it[j].A = sumA[c0 + j]; it[j].n = sumN[c0 + j]; }
+      v = kh_mp_combine(v, it[j]);
+    }
     KhMP total;
     KhMP excl = kh_block_scan_mp(v, s_wtot, &total);
-    KhMP carry = s_carry;
-    if (c < nch) prefix_tmp[c] = kh_mp_combine(carry, excl);
+    const KhMP carry = s_carry;
+    KhMP run = kh_mp_combine(carry, excl);
+#pragma unroll
+    for (int j = 0; j < KH_CARRY_ITEMS; ++j) {
+      if (c0 + j < nch) prefix_tmp[c0 + j] = run;
+      run = kh_mp_combine(run, it[j]);
+    }
     __syncthreads();
     if (tid == 0) s_carry = kh_mp_combine(carry, total);
     __syncthreads();

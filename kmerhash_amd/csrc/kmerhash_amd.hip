@@ -17,7 +17,69 @@
 #include <cstring>
 #include <algorithm>
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
 #define KH_VERSION_STR "kmerhash_amd 0.1 (gfx950)"
+
+// ---- process-wide device memory cache -------------------------------------------------------------
+// hipMalloc/hipFree of multi-GB buffers cost milliseconds to hundreds of milliseconds and synchronise the
+// device; tables are typically created, filled and destroyed in a loop (one per benchmark repeat, one per
+// file batch), so freed table buffers and workspaces are kept and handed out again (best fit).
+namespace {
+struct DevPool {
+  std::mutex m;
+  std::multimap<size_t, void*> free_;                 // size -> block
+  std::unordered_map<void*, size_t> size_of;          // every live or cached block
+  size_t cached = 0;
+};
+DevPool g_pool[16];
+const size_t kPoolGranule = size_t(2) << 20;
+
+void pool_trim(int dev) {
+  DevPool& P = g_pool[dev & 15];
+  std::lock_guard<std::mutex> g(P.m);
+  for (auto& kv : P.free_) { hipFree(kv.second); P.size_of.erase(kv.second); }
+  P.free_.clear();
+  P.cached = 0;
+}
+hipError_t pool_alloc(int dev, size_t bytes, void** out) {
+  DevPool& P = g_pool[dev & 15];
+  bytes = (bytes + kPoolGranule - 1) / kPoolGranule * kPoolGranule;
+  {
+    std::lock_guard<std::mutex> g(P.m);
+    auto it = P.free_.lower_bound(bytes);
+    if (it != P.free_.end() && it->first <= bytes + bytes / 4 + (size_t(16) << 20)) {
+      *out = it->second;
+      P.cached -= it->first;
+      P.free_.erase(it);
+      return hipSuccess;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {            // give cached blocks back to the driver and retry once
+    (void)hipGetLastError();
+    pool_trim(dev);
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> g(P.m);
+  P.size_of[p] = bytes;
+  *out = p;
+  return hipSuccess;
+}
+void pool_free(int dev, void* p) {
+  if (!p) return;
+  DevPool& P = g_pool[dev & 15];
+  std::lock_guard<std::mutex> g(P.m);
+  auto it = P.size_of.find(p);
+  if (it == P.size_of.end()) { hipFree(p); return; }
+  P.free_.insert(std::make_pair(it->second, p));
+  P.cached += it->second;
+}
+}  // namespace
 
 namespace {
 
@@ -78,8 +140,9 @@ kh_status arena_take(kh_table* t, size_t bytes, void** out) {
     ++t->blk; t->off = 0;
   }
   size_t cap = std::max(bytes, size_t(64) << 20);
-  char* p = nullptr;
-  HIPCHK(hipMalloc(&p, cap));
+  void* vp = nullptr;
+  HIPCHK(pool_alloc(t->device, cap, &vp));
+  char* p = static_cast<char*>(vp);
   Block b; b.p = p; b.cap = cap;
   t->blocks.push_back(b);
   t->blk = t->blocks.size() - 1;
@@ -87,19 +150,25 @@ kh_status arena_take(kh_table* t, size_t bytes, void** out) {
   *out = p;
   return KH_OK;
 }
-// after an operation: merge a fragmented arena into one block so that the next call of the same
-// size allocates nothing
-void arena_consolidate(kh_table* t) {
-  if (t->blocks.size() <= 1) return;
+// Before an operation: make the arena ONE block of at least `bytes` (an upper estimate of what the
+// operation takes), so that the steady state allocates nothing; arena_take still grows on demand.
+kh_status arena_prepare(kh_table* t, size_t bytes) {
+  arena_reset(t);
+  if (t->blocks.size() == 1 && t->blocks[0].cap >= bytes) return KH_OK;
   size_t total = 0;
   for (auto& b : t->blocks) total += b.cap;
-  hipStreamSynchronize(t->stream);
-  for (auto& b : t->blocks) hipFree(b.p);
-  t->blocks.clear();
-  char* p = nullptr;
-  if (hipMalloc(&p, total) == hipSuccess) { Block b; b.p = p; b.cap = total; t->blocks.push_back(b); }
-  arena_reset(t);
+  if (!t->blocks.empty()) {
+    hipStreamSynchronize(t->stream);
+    for (auto& b : t->blocks) pool_free(t->device, b.p);
+    t->blocks.clear();
+  }
+  void* p = nullptr;
+  HIPCHK(pool_alloc(t->device, std::max(bytes, total), &p));
+  Block b; b.p = static_cast<char*>(p); b.cap = std::max(bytes, total);
+  t->blocks.push_back(b);
+  return KH_OK;
 }
+void arena_consolidate(kh_table*) {}
 #define TAKE(ptr, type, count)                                                                  \
   do {                                                                                          \
     void* p__ = nullptr;                                                                        \
@@ -110,18 +179,18 @@ void arena_consolidate(kh_table* t) {
 
 // ---- slots ---------------------------------------------------------------------------------------
 uint8_t empty_byte(int kind) { return kind == KHK_RH ? 0x00 : 0x40; }
-void free_slots(KhSlots& s) {
-  if (s.keys) hipFree(s.keys);
-  if (s.vals) hipFree(s.vals);
-  if (s.info) hipFree(s.info);
+void free_slots(kh_table* t, KhSlots& s) {
+  pool_free(t->device, s.keys);
+  pool_free(t->device, s.vals);
+  pool_free(t->device, s.info);
   s.keys = nullptr; s.vals = nullptr; s.info = nullptr; s.cap = 0;
 }
 kh_status alloc_slots(kh_table* t, uint64_t cap, KhSlots& s) {
   s.keys = nullptr; s.vals = nullptr; s.info = nullptr; s.cap = 0;
-  hipError_t e = hipMalloc(&s.keys, std::max<uint64_t>(cap, 8) * 8);
-  if (e == hipSuccess) e = hipMalloc(&s.vals, std::max<uint64_t>(cap, 8) * 4);
-  if (e == hipSuccess) e = hipMalloc(&s.info, cap + 256);
-  if (e != hipSuccess) { free_slots(s); return fail(t, KH_ERR_NOMEM, std::string("table allocation: ") + hipGetErrorString(e)); }
+  hipError_t e = pool_alloc(t->device, std::max<uint64_t>(cap, 8) * 8, reinterpret_cast<void**>(&s.keys));
+  if (e == hipSuccess) e = pool_alloc(t->device, std::max<uint64_t>(cap, 8) * 4, reinterpret_cast<void**>(&s.vals));
+  if (e == hipSuccess) e = pool_alloc(t->device, cap + 256, reinterpret_cast<void**>(&s.info));
+  if (e != hipSuccess) { free_slots(t, s); return fail(t, KH_ERR_NOMEM, std::string("table allocation: ") + hipGetErrorString(e)); }
   s.cap = cap;
   return KH_OK;
 }
@@ -137,7 +206,7 @@ kh_status fresh_slots(kh_table* t, uint64_t cap, KhSlots& s) {
 }
 void retire_slots(kh_table* t, KhSlots& s) {   // keep one spare buffer for ping-pong rebuilds
   if (!s.keys) return;
-  if (t->spare.keys) { hipStreamSynchronize(t->stream); free_slots(t->spare); }
+  if (t->spare.keys) { hipStreamSynchronize(t->stream); free_slots(t, t->spare); }
   t->spare = s;
   s = KhSlots{nullptr, nullptr, nullptr, 0};
 }
@@ -194,6 +263,9 @@ kh_status stage_in(kh_table* t, const void* p, uint64_t n, kh_mem where, const T
   *out = d;
   return KH_OK;
 }
+
+// workspace a rebuild at capacity `cap` takes (home counts + per-chunk scan arrays)
+inline size_t ws_rebuild(uint64_t cap) { return size_t(cap) * 2 + (cap > KH_L ? (cap >> KH_LB) : 1) * 48 + (size_t(1) << 16); }
 
 // ---- chunk rebuild ---------------------------------------------------------------------------------
 // Lays out (live elements of t->cur, minus `erased`) U (new distinct elements) at capacity new_cap in
@@ -261,7 +333,7 @@ kh_status do_rehash(kh_table* t, uint64_t b) {
   } else if (t->lsize > n) {
     return fail(t, KH_ERR_FULL, "ERROR: did not find any place to insert.  should not have happend (hashmap_linearprobe.hpp:408)");
   }
-  arena_reset(t);
+  { kh_status ps = arena_prepare(t, ws_rebuild(n)); if (ps != KH_OK) return ps; }
   kh_status st = rebuild(t, n, nullptr, nullptr, nullptr, 0, nullptr, t->lsize);
   arena_consolidate(t);
   return st;
@@ -303,7 +375,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts1, (uint64_t)nb1, off1); }
   HIPCHK(hipMemcpyAsync(cur1, off1, sizeof(uint64_t) * nb1, hipMemcpyDeviceToDevice, t->stream));
   { Launch L(t, "k_part_scatter");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 4 + nb1 * 8, t->stream, P)); }
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
   if (B2 == 0) {
     out.rk = ak; out.rv = av; out.ri = ai; out.part_off = off1; out.PB = PB; out.nparts = nparts;
     out.spare_k = bk; out.spare_v = bv; out.spare_i = bi;
@@ -329,7 +401,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts2, (uint64_t)nparts, off2); }
   HIPCHK(hipMemcpyAsync(cur2, off2, sizeof(uint64_t) * nparts, hipMemcpyDeviceToDevice, t->stream));
   { Launch L(t, "k_part_scatter");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 4 + nb2 * 8, t->stream, Q)); }
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
   HIPCHK(hipGetLastError());
   out.rk = bk; out.rv = bv; out.ri = bi; out.part_off = off2; out.PB = PB; out.nparts = nparts;
   out.spare_k = ak; out.spare_v = av; out.spare_i = ai;
@@ -410,7 +482,9 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
   if (n_inserted) *n_inserted = 0;
   if (n && !keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
-  arena_reset(t);
+  { const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n ? n : 1, n, n ? n - 1 : 0);
+    kh_status ps = arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_rebuild(cu) + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
+    if (ps != KH_OK) return ps; }
   const char* kb = static_cast<const char*>(keys);
   const char* vb = static_cast<const char*>(vals);
   if (where == KH_MEM_HOST && n) {
@@ -487,7 +561,7 @@ kh_status do_find(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint3
   if (n == 0) return KH_OK;
   if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
-  arena_reset(t);
+  { kh_status ps = arena_prepare(t, n * 40 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
   const uint64_t* q;
   kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
   if (st != KH_OK) return st;
@@ -537,7 +611,7 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
   if (n == 0) return KH_OK;
   if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
-  arena_reset(t);
+  { kh_status ps = arena_prepare(t, n * 8 + t->cur.cap / 8 + ws_rebuild(t->cur.cap) + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
   const uint64_t* q;
   kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
   if (st != KH_OK) return st;
@@ -575,6 +649,14 @@ extern "C" {
 
 const char* kh_version(void) { return KH_VERSION_STR; }
 
+kh_status kh_release_cached_memory(int device) {
+  if (device < 0 || device >= 16) return KH_ERR_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return KH_ERR_HIP;
+  hipDeviceSynchronize();
+  pool_trim(device);
+  return KH_OK;
+}
+
 kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t val_bytes, kh_hash hash, uint64_t seed,
                     uint64_t capacity, float min_lf, float max_lf, int device) {
   if (!out) return KH_ERR_INVALID;
@@ -592,8 +674,8 @@ kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t v
   t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false;
   const uint64_t cap = next_pow2(capacity);
   if (alloc_slots(t, cap, t->cur) != KH_OK) { delete t; return KH_ERR_NOMEM; }
-  if (hipHostMalloc(reinterpret_cast<void**>(&t->hpin), 64 * sizeof(uint64_t)) != hipSuccess) { free_slots(t->cur); delete t; return KH_ERR_NOMEM; }
-  if (hipMemset(t->cur.info, empty_byte(t->kind), cap + 256) != hipSuccess) { free_slots(t->cur); hipHostFree(t->hpin); delete t; return KH_ERR_HIP; }
+  if (hipHostMalloc(reinterpret_cast<void**>(&t->hpin), 64 * sizeof(uint64_t)) != hipSuccess) { free_slots(t, t->cur); delete t; return KH_ERR_NOMEM; }
+  if (hipMemset(t->cur.info, empty_byte(t->kind), cap + 256) != hipSuccess) { free_slots(t, t->cur); hipHostFree(t->hpin); delete t; return KH_ERR_HIP; }
   t->min_load = threshold(cap, min_lf);
   t->max_load = threshold(cap, max_lf);
   *out = t;
@@ -605,8 +687,8 @@ kh_status kh_destroy(kh_table* t) {
   hipSetDevice(t->device);
   hipStreamSynchronize(t->stream);
   for (auto& r : t->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
-  free_slots(t->cur); free_slots(t->spare);
-  for (auto& b : t->blocks) hipFree(b.p);
+  free_slots(t, t->cur); free_slots(t, t->spare);
+  for (auto& b : t->blocks) pool_free(t->device, b.p);
   if (t->hpin) hipHostFree(t->hpin);
   delete t;
   return KH_OK;
@@ -666,7 +748,7 @@ kh_status kh_count(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint
   if (n == 0) return KH_OK;
   if (!keys || !out01) return fail(t, KH_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(t->device));
-  arena_reset(t);
+  { kh_status ps = arena_prepare(t, n * 9 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
   const uint64_t* q;
   kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
   if (st != KH_OK) return st;
@@ -724,7 +806,7 @@ kh_status kh_erase_one(kh_table* t, uint64_t key, uint64_t* n_erased) {
 kh_status kh_to_vector(kh_table* t, uint64_t* keys_host, uint32_t* vals_host, uint64_t* n_out) {
   if (!t) return KH_ERR_INVALID;
   HIPCHK(hipSetDevice(t->device));
-  arena_reset(t);
+  { kh_status ps = arena_prepare(t, t->cur.cap * 14 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
   const uint64_t cap = t->cur.cap;
   uint8_t* flags; uint64_t* ck; uint32_t* cv;
   TAKE(flags, uint8_t, cap); TAKE(ck, uint64_t, cap); TAKE(cv, uint32_t, cap);
@@ -761,7 +843,7 @@ kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]) {
   for (int i = 0; i < 128; ++i) out[i] = 0;
   if (t->kind != KHK_RH) return KH_OK;
   HIPCHK(hipSetDevice(t->device));
-  arena_reset(t);
+  { kh_status ps = arena_prepare(t, size_t(1) << 20); if (ps != KH_OK) return ps; }
   unsigned long long* d;
   TAKE(d, unsigned long long, 128);
   HIPCHK(hipMemsetAsync(d, 0, 128 * 8, t->stream));

@@ -1,0 +1,108 @@
+// C++ side of the drop-in boundary: the reference's own test strategy (test/unit/test_hashmap_robinhood_doubling.cpp
+// :97-334, test_hashmap_linearprobe_doubling.cpp:84-195) written against the shim: differential against
+// std::unordered_map::emplace (first value wins), through the reference's member names.  The map type is passed
+// as a 5-parameter template-template exactly as BenchmarkHashTables.cpp:1037-1048 does.
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
+#include <random>
+#include <unordered_map>
+#include <vector>
+
+#include "kmerhash/hashmap_robinhood.hpp"
+#include "kmerhash/hashmap_linearprobe.hpp"
+
+#define CHECK(c) do { if (!(c)) { std::printf("CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+// a Kmer-like key: 8-byte trivially copyable wrapper of one word (bliss::common::Kmer<31,DNA,uint64_t> shape)
+struct Kmer31 {
+  uint64_t data;
+  Kmer31() : data(0) {}
+  explicit Kmer31(uint64_t d) : data(d) {}
+  bool operator==(Kmer31 const& o) const { return data == o.data; }
+  bool operator<(Kmer31 const& o) const { return data < o.data; }
+};
+namespace std { template <> struct hash<Kmer31> { size_t operator()(Kmer31 const& k) const { return k.data; } }; }
+
+template <template <typename, typename, typename, typename, typename> class MAP, typename Key, typename Hash>
+void differential(const char* name, size_t n, bool is_rh) {
+  using Map = MAP<Key, uint32_t, Hash, ::std::equal_to<Key>, ::std::allocator<::std::pair<Key, uint32_t> > >;
+  std::default_random_engine gen(17);
+  std::uniform_int_distribution<uint64_t> dist(2, (uint64_t(1) << 62) - 2);
+  std::vector<std::pair<Key, uint32_t> > input;
+  std::unordered_map<uint64_t, uint32_t> gold;
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t k = dist(gen);
+    if (i % 3 == 0 && !input.empty()) k = kmerhash_amd::detail::key_bits(input[gen() % input.size()].first);
+    input.push_back(std::make_pair(Key(k), uint32_t(i)));
+    gold.emplace(k, uint32_t(i));
+  }
+  Map map;
+  map.set_min_load_factor(0.35f);
+  map.set_max_load_factor(0.8f);
+  map.insert(input);
+  CHECK(map.size() == gold.size());
+  // sorted to_vector() == sorted gold
+  auto v = map.to_vector();
+  CHECK(v.size() == gold.size());
+  for (auto& kv : v) { auto it = gold.find(kmerhash_amd::detail::key_bits(kv.first)); CHECK(it != gold.end() && it->second == kv.second); }
+  // iteration over begin()/end()
+  size_t cnt = 0;
+  for (auto it = map.begin(); it != map.end(); ++it) { CHECK(gold.count(kmerhash_amd::detail::key_bits(it->first)) == 1); ++cnt; }
+  CHECK(cnt == gold.size());
+  // single-key count / find, batch count over pairs and over keys, batch find
+  size_t q = std::min<size_t>(n / 2 + 1, input.size());
+  std::vector<Key> qk;
+  for (size_t i = 0; i < q; ++i) qk.push_back(input[i].first);
+  for (size_t i = 0; i < 50; ++i) qk.push_back(Key(dist(gen) | (uint64_t(1) << 63)));   // misses
+  auto counts = map.count(qk.begin(), qk.end());
+  auto counts2 = map.count(input.begin(), input.begin() + q);
+  CHECK(counts.size() == qk.size() && counts2.size() == q);
+  for (size_t i = 0; i < qk.size(); ++i) CHECK(counts[i] == gold.count(kmerhash_amd::detail::key_bits(qk[i])));
+  for (size_t i = 0; i < q; ++i) CHECK(counts2[i] == 1);
+  auto found = map.find(qk.begin(), qk.end());
+  CHECK(found.size() == q);
+  for (size_t i = 0; i < q; ++i) { CHECK(found[i].first == qk[i]); CHECK(found[i].second == gold[kmerhash_amd::detail::key_bits(qk[i])]); }
+  CHECK(map.count(qk[0]) == 1 && map.count(qk.back()) == 0);
+  CHECK(map.find(qk[0]) != map.end() && map.find(qk[0])->second == gold[kmerhash_amd::detail::key_bits(qk[0])]);
+  CHECK(map.find(qk.back()) == map.end());
+  // insert(key,val) duplicate keeps the first value; update overwrites
+  auto r = map.insert(qk[0], 4242u);
+  CHECK(!r.second && r.first->second == gold[kmerhash_amd::detail::key_bits(qk[0])]);
+  CHECK(map.update(qk[0], 4242u)->second == 4242u);
+  // erase first half: size equality, erased keys gone, kept keys present
+  std::vector<Key> uniq;
+  for (auto& kv : gold) uniq.push_back(Key(kv.first));
+  std::sort(uniq.begin(), uniq.end());
+  size_t half = uniq.size() / 2;
+  CHECK(map.erase(uniq.begin(), uniq.begin() + half) == half);
+  CHECK(map.size() == uniq.size() - half);
+  auto c3 = map.count(uniq.begin(), uniq.end());
+  for (size_t i = 0; i < uniq.size(); ++i) CHECK(c3[i] == (i < half ? 0u : 1u));
+  CHECK(map.erase(uniq[half]) == 1 && map.erase(uniq[half]) == 0);
+  if (is_rh) CHECK(map.capacity() >= map.size());
+  map.clear();
+  CHECK(map.size() == 0 && map.begin() == map.end());
+  std::printf("%s ok (n=%zu, distinct=%zu)\n", name, n, gold.size());
+}
+
+int main() {
+  differential<fsc::hashmap_robinhood_doubling, uint64_t, fsc::hash::murmur3avx64<uint64_t> >("rh/u64/murmur3avx64", 100000, true);
+  differential<fsc::hashmap_robinhood_doubling, uint64_t, std::hash<uint64_t> >("rh/u64/std::hash", 20000, true);
+  differential<fsc::hashmap_robinhood_doubling, Kmer31, fsc::hash::farm<Kmer31> >("rh/Kmer31/farm", 30000, true);
+  differential<fsc::hashmap_robinhood_doubling, Kmer31, fsc::hash::murmur<Kmer31> >("rh/Kmer31/murmur", 30000, true);
+  differential<fsc::hashmap_linearprobe_doubling, uint64_t, fsc::hash::murmur3avx64<uint64_t> >("lp/u64/murmur3avx64", 100000, false);
+  differential<fsc::hashmap_linearprobe_doubling, Kmer31, fsc::hash::identity<Kmer31> >("lp/Kmer31/identity", 5000, false);
+  // the host operator() of the functors agrees with the device batch hash (used by callers that pre-hash)
+  {
+    std::vector<uint64_t> k(1000), out(1000);
+    for (size_t i = 0; i < k.size(); ++i) k[i] = i * 0x9E3779B97F4A7C15ull + 1;
+    fsc::hash::murmur3avx64<uint64_t> h(43);
+    CHECK(kh_hash_batch(KH_HASH_MURMUR3_X86_128_LO64, 43, k.data(), k.size(), KH_MEM_HOST, out.data(), 0, nullptr) == KH_OK);
+    for (size_t i = 0; i < k.size(); ++i) CHECK(out[i] == h(k[i]));
+    CHECK(h(uint64_t(1)) == 0xdbcde6617f85bf2aull);
+    CHECK(fsc::hash::murmur<uint64_t>(43)(uint64_t(1)) == 0x252c590efc7e7503ull);
+  }
+  std::printf("all shim tests passed\n");
+  return 0;
+}

@@ -237,3 +237,31 @@ def test_sentinel_key_values(oracle):
         check_state(g, o, kind)
         check_queries(g, o, np.array([0, 5, 0xFFFFFFFFFFFFFFFF, 2**63, 3], dtype=np.uint64))
         g.close()
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 8])
+def test_shard_permute_is_stable_partition_by_rank(oracle, p):
+    """rank = murmur3(key, seed 9876543) & (p-1) (power of two) or % p; order kept inside a rank"""
+    from kmerhash_amd.dist import GpuBackend, DIST_SEED
+    keys, vals = W.w1_benchmark_hashtables(150_001, seed=8)
+    be = GpuBackend(0)
+    ok, ov, counts = be.shard(dev(keys), dev(vals), p)
+    r = (oracle.hash_batch(1, DIST_SEED, keys) % np.uint64(p)).astype(np.int64)
+    order = np.argsort(r, kind="stable")
+    assert counts == np.bincount(r, minlength=p).tolist()
+    assert np.array_equal(host(ok, np.uint64), keys[order])
+    assert np.array_equal(host(ov, np.uint32), vals[order])
+    be.table.close()
+
+
+def test_sharded_table_single_rank(oracle):
+    from kmerhash_amd.dist import GpuBackend, ShardedTable
+    keys, vals = W.w1_benchmark_hashtables(50_000, seed=12)
+    be = GpuBackend(0)
+    st = ShardedTable(be)
+    o = oracle.OracleTable(0, 128, 0.35, 0.8)
+    assert st.insert(dev(keys), dev(vals)) == o.insert(keys, vals)
+    check_state(be.table, o, 0)
+    pk, c = st.count(dev(keys[:1000]))
+    assert bool(c.all()) and st.size() == o.size()
+    be.table.close()
