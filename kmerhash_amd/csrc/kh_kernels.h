@@ -250,8 +250,8 @@ struct KhTile { uint64_t beg; uint32_t len; uint32_t seg; };
 
 struct KhPartParams {
   const char* kbase; uint32_t kstride;     // input keys (stride 8 = SoA, 16 = pair array)
-  const char* vbase; uint32_t vstride;     // input values (may be null: value = 0)
-  const uint32_t* idx;                     // input original index (null: position)
+  const char* vbase; uint32_t vstride;     // first pass: input values (may be null: value = 0); iv = position<<32 | value
+  const unsigned long long* iv_in;         // later passes: iv of the input records
   uint64_t n;                              // number of input records
   const KhTile* tiles;                     // null: arithmetic tiles of KH_PART_TILE over [0,n), seg 0
   const uint32_t* ntiles_dev;              // with tiles: actual tile count
@@ -262,7 +262,7 @@ struct KhPartParams {
   uint32_t nb;                             // bins in this pass (power of two, <= 2048)
   uint32_t* counts;                        // [nseg*nb] histogram (hist kernel)
   unsigned long long* cursor;              // [nseg*nb] running output offsets (scatter kernel)
-  uint64_t* ok; uint32_t* ov; uint32_t* oi;// output records
+  uint64_t* ok; unsigned long long* oiv;   // output records
 };
 
 // partition id of a hash: chunk id at the partitioning capacity, bit-reversed so that the
@@ -331,8 +331,7 @@ template <int HASH>
 __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P) {
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
   __shared__ uint64_t lk[KH_PART_TILE];
-  __shared__ uint32_t lv[KH_PART_TILE];
-  __shared__ uint32_t li[KH_PART_TILE];
+  __shared__ unsigned long long liv[KH_PART_TILE];
   __shared__ uint16_t ld[KH_PART_TILE];
   __shared__ uint32_t wtot[KH_PART_THREADS / 64];
   const uint32_t nb = P.nb;
@@ -346,14 +345,16 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
   for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) hist[i] = 0;
   __syncthreads();
   uint64_t key[KH_PART_ITEMS];
-  uint32_t val[KH_PART_ITEMS], idx[KH_PART_ITEMS], dg[KH_PART_ITEMS], rk[KH_PART_ITEMS];
+  unsigned long long iv[KH_PART_ITEMS];
+  uint32_t dg[KH_PART_ITEMS], rk[KH_PART_ITEMS];
 #pragma unroll
   for (int j = 0; j < KH_PART_ITEMS; ++j) {
     uint32_t i = tid + j * KH_PART_THREADS;
     if (i < d.len) {
       key[j] = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
-      val[j] = P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : 0u;
-      idx[j] = P.idx ? P.idx[d.beg + i] : (uint32_t)(d.beg + i);
+      if (P.iv_in) iv[j] = P.iv_in[d.beg + i];
+      else iv[j] = ((unsigned long long)(d.beg + i) << 32) |
+                   (P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : 0u);
       uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
       dg[j] = (q >> P.shift) & (nb - 1);
       rk[j] = atomicAdd(&hist[dg[j]], 1u);
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
     uint32_t i = tid + j * KH_PART_THREADS;
     if (i < d.len) {
       uint32_t s = loff[dg[j]] + rk[j];
-      lk[s] = key[j]; lv[s] = val[j]; li[s] = idx[j]; ld[s] = (uint16_t)dg[j];
+      lk[s] = key[j]; liv[s] = iv[j]; ld[s] = (uint16_t)dg[j];
     }
   }
   __syncthreads();
@@ -396,8 +397,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
     uint32_t dd = ld[s];
     uint64_t pos = gbase[dd] + (s - loff[dd]);
     P.ok[pos] = lk[s];
-    P.ov[pos] = lv[s];
-    P.oi[pos] = li[s];
+    P.oiv[pos] = liv[s];
   }
 }
 
@@ -439,17 +439,36 @@ __global__ void k_make_tiles(const uint64_t* __restrict__ segoff, uint32_t nseg,
   if (tid == 0) *ntiles_out = carry_s;
 }
 
+
+// wave-aggregated append: lanes with `want` get consecutive positions from *counter (one LDS atomic per wave)
+__device__ __forceinline__ uint32_t kh_wave_append(bool want, uint32_t* counter) {
+  const unsigned long long m = __ballot(want);
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (m) {
+    const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, (int)leader, 64);
+  }
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ uint32_t kh_wave_max(uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: per-partition first-wins de-duplication in LDS + membership test against the current table.
 // Emits the batch's DISTINCT NEW keys (with the value of their first occurrence).
 // ---------------------------------------------------------------------------------------------
 struct KhDedupParams {
-  const uint64_t* rk; const uint32_t* rv; const uint32_t* ri;   // partitioned records
+  const uint64_t* rk; const unsigned long long* riv;            // partitioned records (key, idx<<32|val)
   const uint64_t* part_off;                                      // [nparts+1]
-  uint64_t* nk; uint32_t* nv; uint32_t* ni;                      // outputs, written at part_off[q] + j
+  uint64_t* nk; uint32_t* nv;                                    // outputs, written at part_off[q] + j
   uint32_t* cnt_new;                                             // [nparts]
   unsigned long long* max_idx_plus1;                             // max (first-occurrence index + 1) over new keys
   KhSlots T; uint64_t seed;
+  int table_empty;                                               // size() == 0: skip the membership probes
   int last_wins;                                                 // 0: insert (first value wins, emit keys the table lacks)
                                                                  // 1: kh_update assign pass (last value wins, written in place)
   uint32_t* flags;
@@ -459,8 +478,9 @@ template <int KIND, int HASH>
 __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ unsigned long long skey[KH_HS];
   __shared__ unsigned long long siv[KH_HS];
-  __shared__ unsigned long long special_iv;
-  __shared__ uint32_t out_count, overflow, max_idx;
+  __shared__ uint16_t claimed[KH_HS];           // slots claimed in this round (the distinct keys)
+  __shared__ unsigned long long special_iv;     // the key 0xFFFF...F (the set's empty marker) is kept out of band
+  __shared__ uint32_t n_claimed, special_seen, out_count, overflow, max_idx;
   const uint32_t tid = threadIdx.x;
   const uint32_t q = blockIdx.x;
   const uint64_t beg = P.part_off[q];
@@ -468,58 +488,77 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   const uint64_t mask = P.T.cap - 1;
   const unsigned long long iv_init = P.last_wins ? 0ull : ~0ull;
   if (m == 0) { if (tid == 0) P.cnt_new[q] = 0; return; }
-  uint32_t R = (m + KH_HS / 2 - 1) / (KH_HS / 2);   // classes: at most HS/2 records each on average
+  uint32_t R = (m + KH_HS / 2 - 1) / (KH_HS / 2);   // key classes: at most HS/2 records each on average
   bool done = false;
   while (!done) {
     if (tid == 0) { out_count = 0; overflow = 0; max_idx = 0; }
     for (uint32_t r = 0; r < R; ++r) {
       for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) { skey[s] = KH_EMPTY_KEY; siv[s] = iv_init; }
-      if (tid == 0) special_iv = iv_init;
+      if (tid == 0) { special_iv = iv_init; special_seen = 0; n_claimed = 0; }
       __syncthreads();
-      for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) {
-        unsigned long long key = P.rk[beg + i];
-        uint64_t f = kh_fmix64(key + 0x9E3779B97F4A7C15ull);
-        if (R > 1 && (uint32_t)((f >> 32) % R) != r) continue;
-        // with last_wins the priority is idx+1 (so that 0 means "none"); idx < 2^32-1 is enforced by the host
-        unsigned long long iv = ((unsigned long long)(P.ri[beg + i] + (P.last_wins ? 1u : 0u)) << 32) | P.rv[beg + i];
-        if (key == KH_EMPTY_KEY) {
-          if (P.last_wins) atomicMax(&special_iv, iv); else atomicMin(&special_iv, iv);
-          continue;
-        }
-        uint32_t slot = (uint32_t)f & (KH_HS - 1);
-        uint32_t probe = 0;
-        for (; probe < KH_HS; ++probe) {
-          unsigned long long cur = skey[slot];
-          if (cur == KH_EMPTY_KEY) cur = atomicCAS(&skey[slot], KH_EMPTY_KEY, key), cur = (cur == KH_EMPTY_KEY) ? key : cur;
-          if (cur == key) {
-            if (P.last_wins) atomicMax(&siv[slot], iv); else atomicMin(&siv[slot], iv);
-            break;
+      for (uint32_t i0 = 0; i0 < m; i0 += KH_CHUNK_THREADS) {     // wave-uniform trip count (ballots below)
+        const uint32_t i = i0 + tid;
+        int claimed_slot = -1;
+        if (i < m) {
+          const unsigned long long key = P.rk[beg + i];
+          const unsigned long long iv = P.riv[beg + i];
+          const uint64_t f = kh_fmix64(key + 0x9E3779B97F4A7C15ull);
+          if (R == 1 || (uint32_t)((f >> 32) % R) == r) {
+            if (key == KH_EMPTY_KEY) {
+              special_seen = 1;
+              if (P.last_wins) atomicMax(&special_iv, iv); else atomicMin(&special_iv, iv);
+            } else {
+              uint32_t slot = (uint32_t)f & (KH_HS - 1);
+              uint32_t probe = 0;
+              for (; probe < KH_HS; ++probe) {
+                unsigned long long cur = skey[slot];
+                if (cur == KH_EMPTY_KEY) {
+                  cur = atomicCAS(&skey[slot], KH_EMPTY_KEY, key);
+                  if (cur == KH_EMPTY_KEY) { claimed_slot = (int)slot; cur = key; }
+                }
+                if (cur == key) {
+                  if (P.last_wins) atomicMax(&siv[slot], iv); else atomicMin(&siv[slot], iv);
+                  break;
+                }
+                slot = (slot + 1) & (KH_HS - 1);
+              }
+              if (probe == KH_HS) overflow = 1;
+            }
           }
-          slot = (slot + 1) & (KH_HS - 1);
         }
-        if (probe == KH_HS) overflow = 1;
+        const uint32_t at = kh_wave_append(claimed_slot >= 0, &n_claimed);
+        if (claimed_slot >= 0) claimed[at] = (uint16_t)claimed_slot;
       }
       __syncthreads();
       if (overflow) break;
-      // emit distinct keys of this class that the table does not hold yet
-      for (uint32_t s = tid; s < KH_HS + 1; s += KH_CHUNK_THREADS) {
-        unsigned long long key, iv;
-        if (s < KH_HS) { key = skey[s]; iv = siv[s]; if (key == KH_EMPTY_KEY) continue; }
-        else { key = KH_EMPTY_KEY; iv = special_iv; if (iv == iv_init) continue; }
-        uint64_t h = kh_hash64<HASH>(key, P.seed);
-        uint64_t at = kh_find_pos<KIND>(P.T.keys, P.T.info, mask, h & mask, key);
-        if (P.last_wins) {   // kh_update's assign pass: every key is present by now; store its LAST value
-          if (at != KH_NONE) P.T.vals[at] = (uint32_t)iv;
-          continue;
+      // the distinct keys of this class: test membership in the current table, emit the new ones
+      const uint32_t nd = n_claimed + (special_seen ? 1u : 0u);
+      uint32_t my_max = 0;
+      for (uint32_t j0 = 0; j0 < nd; j0 += KH_CHUNK_THREADS) {
+        const uint32_t j = j0 + tid;
+        bool emit = false;
+        unsigned long long key = 0, iv = 0;
+        if (j < nd) {
+          if (j < n_claimed) { const uint32_t s = claimed[j]; key = skey[s]; iv = siv[s]; }
+          else { key = KH_EMPTY_KEY; iv = special_iv; }
+          uint64_t at = KH_NONE;
+          if (!P.table_empty) {
+            const uint64_t h = kh_hash64<HASH>(key, P.seed);
+            at = kh_find_pos<KIND>(P.T.keys, P.T.info, mask, h & mask, key);
+          }
+          if (P.last_wins) { if (at != KH_NONE) P.T.vals[at] = (uint32_t)iv; }   // kh_update's assign pass: store the LAST value
+          else emit = at == KH_NONE;
         }
-        if (at != KH_NONE) continue;
-        uint32_t pos = atomicAdd(&out_count, 1u);
-        uint32_t idx = (uint32_t)(iv >> 32) - (P.last_wins ? 1u : 0u);
-        P.nk[beg + pos] = key;
-        P.nv[beg + pos] = (uint32_t)iv;
-        P.ni[beg + pos] = idx;
-        atomicMax(&max_idx, idx + 1u);   // only meaningful for first-wins (insert)
+        const uint32_t pos = kh_wave_append(emit, &out_count);
+        if (emit) {
+          P.nk[beg + pos] = key;
+          P.nv[beg + pos] = (uint32_t)iv;
+          const uint32_t ix = (uint32_t)(iv >> 32) + 1u;
+          my_max = ix > my_max ? ix : my_max;
+        }
       }
+      my_max = kh_wave_max(my_max);
+      if ((tid & 63) == 0 && my_max) atomicMax(&max_idx, my_max);
       __syncthreads();
     }
     if (overflow) { R *= 2; __syncthreads(); if (R > m) { if (tid == 0) atomicOr(&P.flags[KH_FLAG_INTERNAL], 1u); break; } }
@@ -548,8 +587,9 @@ struct KhRebuildParams {
   KhSlots Old;                       // source table
   const uint32_t* erased_bits;       // optional: slots to drop (RH erase)
   KhSlots New;                       // destination table (info pre-set to "empty")
-  const uint64_t* ck; const uint32_t* cv;   // new distinct elements, partition order
-  const uint64_t* noff;              // [nparts+1] offsets into ck/cv (null: no new elements)
+  const uint64_t* ck; const uint32_t* cv;   // new distinct elements, grouped by partition
+  const uint64_t* noff;              // [nparts+1] start of every partition's list in ck/cv (null: no new elements)
+  const uint32_t* ncnt;              // per-partition list length; null: lists are dense (length = noff[q+1]-noff[q])
   uint32_t PB;                       // partition bits the new elements were grouped with
   uint64_t seed;
   uint16_t* homecnt;                 // [New.cap] elements per home bucket
@@ -565,6 +605,7 @@ __device__ __forceinline__ uint32_t kh_log2u(uint64_t x) { return 63u - (uint32_
 template <int KIND, int HASH, typename F>
 __device__ __forceinline__ void kh_for_each_old(const KhRebuildParams& P, uint32_t c, uint32_t* s_emin, F f) {
   const uint32_t tid = threadIdx.x;
+  if (P.Old.cap == 0) return;            // the host passes cap 0 for an empty source table
   const uint64_t cap_o = P.Old.cap, mask_o = cap_o - 1, mask_n = P.New.cap - 1;
   const uint32_t nch_o = cap_o > KH_L ? (uint32_t)(cap_o >> KH_LB) : 1u;
   const uint32_t nch_n = P.New.cap > KH_L ? (uint32_t)(P.New.cap >> KH_LB) : 1u;
@@ -602,15 +643,34 @@ __device__ __forceinline__ void kh_for_each_old(const KhRebuildParams& P, uint32
   __syncthreads();
 }
 
-// range of the contiguous new-element list that belongs to new chunk c
-__device__ __forceinline__ void kh_new_range(const KhRebuildParams& P, uint32_t c, uint64_t& b, uint64_t& e) {
-  if (!P.noff) { b = e = 0; return; }
+// Calls f(key, val, home_new) for every new element whose home lies in new chunk c.  The elements were grouped
+// by the bit-reversed chunk id of the partitioning capacity, so a chunk of any smaller-or-equal capacity owns a
+// contiguous run of partitions [q0, q0 + 2^(PB-k)).
+template <int HASH, typename F>
+__device__ __forceinline__ void kh_for_each_new(const KhRebuildParams& P, uint32_t c, F f) {
+  if (!P.noff) return;
+  const uint64_t mask_n = P.New.cap - 1;
   const uint32_t nch_n = P.New.cap > KH_L ? (uint32_t)(P.New.cap >> KH_LB) : 1u;
   const uint32_t k = kh_log2u(nch_n);
   const uint32_t span_bits = P.PB - k;                    // PB >= k by construction
   const uint32_t q0 = k ? ((__brev(c) >> (32 - k)) << span_bits) : 0u;
-  b = P.noff[q0];
-  e = P.noff[q0 + (1u << span_bits)];
+  const uint32_t q1 = q0 + (1u << span_bits);
+  if (!P.ncnt) {                                           // dense: one contiguous range
+    const uint64_t b = P.noff[q0], e = P.noff[q1];
+    for (uint64_t i = b + threadIdx.x; i < e; i += KH_CHUNK_THREADS) {
+      const uint64_t key = P.ck[i];
+      f(key, P.cv[i], kh_hash64<HASH>(key, P.seed) & mask_n);
+    }
+  } else {                                                 // a few per-partition lists (span is small)
+    for (uint32_t q = q0; q < q1; ++q) {
+      const uint64_t b = P.noff[q];
+      const uint32_t n = P.ncnt[q];
+      for (uint32_t i = threadIdx.x; i < n; i += KH_CHUNK_THREADS) {
+        const uint64_t key = P.ck[b + i];
+        f(key, P.cv[b + i], kh_hash64<HASH>(key, P.seed) & mask_n);
+      }
+    }
+  }
 }
 
 // (max,+) composite: f(x) = max(A, x + n); combine(first, then) = then o first
@@ -663,12 +723,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_count(KhRebuildParam
   for (uint32_t i = tid; i < KH_L; i += KH_CHUNK_THREADS) cnt[i] = 0;
   __syncthreads();
   kh_for_each_old<KIND, HASH>(P, c, &s_emin, [&](uint64_t, uint32_t, uint64_t hn) { atomicAdd(&cnt[hn - Sc], 1u); });
-  uint64_t nb, ne;
-  kh_new_range(P, c, nb, ne);
-  for (uint64_t i = nb + tid; i < ne; i += KH_CHUNK_THREADS) {
-    uint64_t hn = kh_hash64<HASH>(P.ck[i], P.seed) & mask_n;
-    atomicAdd(&cnt[hn - Sc], 1u);
-  }
+  kh_for_each_new<HASH>(P, c, [&](uint64_t, uint32_t, uint64_t hn) { atomicAdd(&cnt[hn - Sc], 1u); });
   __syncthreads();
   // per-thread composite over its consecutive homes, relative to the chunk start
   KhMP v; v.A = KH_MP_NEG; v.n = 0;
@@ -733,15 +788,28 @@ __global__ void k_chunk_carry(const long long* __restrict__ sumA, const long lon
   }
 }
 
+// K3.  The chunk's slice of the new table is assembled in LDS and streamed out: the workgroup owns the slots
+// [S_c + carry_in, S_c + max(L, end)) -- its own L home buckets minus what the previous chunks ran over into, plus
+// its own run-over -- so the slices of all workgroups tile the (circular) table exactly once and every info byte,
+// occupied or empty, is written by exactly one workgroup with coalesced stores.
+#define KH_SPILL 256     // run-over slots staged in LDS; anything further out (only LP clusters) is stored directly
 template <int KIND, int HASH>
 __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParams P) {
+  __shared__ uint64_t skeys[KH_L + KH_SPILL];
+  __shared__ uint32_t svals[KH_L + KH_SPILL];
+  __shared__ uint32_t sinfo_w[(KH_L + KH_SPILL) / 4];
   __shared__ uint32_t fill[KH_L];
   __shared__ uint32_t start[KH_L];
   __shared__ uint32_t s_emin;
+  __shared__ long long s_pend;
   __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
+  uint8_t* sinfo = reinterpret_cast<uint8_t*>(sinfo_w);
   const uint32_t tid = threadIdx.x, c = blockIdx.x;
   const uint32_t Ln = P.New.cap > KH_L ? KH_L : (uint32_t)P.New.cap;
   const uint64_t Sc = (uint64_t)c * Ln, mask_n = P.New.cap - 1;
+  const uint32_t empty4 = KIND == KHK_RH ? 0u : 0x40404040u;
+  for (uint32_t i = tid; i < KH_L + KH_SPILL; i += KH_CHUNK_THREADS) { skeys[i] = 0; svals[i] = 0; }
+  for (uint32_t i = tid; i < (KH_L + KH_SPILL) / 4; i += KH_CHUNK_THREADS) sinfo_w[i] = empty4;
   uint32_t cb[KH_HOMES_PER_THREAD];
   KhMP v; v.A = KH_MP_NEG; v.n = 0;
 #pragma unroll
@@ -752,7 +820,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParam
     fill[tid * KH_HOMES_PER_THREAD + j] = 0;
   }
   KhMP excl = kh_block_scan_mp(v, s_wtot, nullptr);
-  long long xr = P.xcarry[c] - (long long)Sc;          // carry-in relative to the chunk start (<= 0: none)
+  const long long xr = P.xcarry[c] - (long long)Sc;          // carry-in relative to the chunk start (<= 0: none)
   long long p = excl.A > xr + excl.n ? excl.A : xr + excl.n;
 #pragma unroll
   for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
@@ -763,28 +831,38 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParam
       p = st + cb[j];
     }
   }
+  if (tid == KH_CHUNK_THREADS - 1) s_pend = p;     // homes are owned in thread order: the last lane holds the end
   __syncthreads();
   auto place = [&](uint64_t key, uint32_t val, uint64_t hn) {
     uint32_t b = (uint32_t)(hn - Sc);
     uint32_t r = atomicAdd(&fill[b], 1u);
     uint32_t prel = start[b] + r;
     uint32_t dist = prel - b;
-    uint64_t pos = (Sc + prel) & mask_n;
-    P.New.keys[pos] = key;
-    P.New.vals[pos] = val;
+    uint8_t ib = 0x00;
     if (KIND == KHK_RH) {
       if (dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
-      P.New.info[pos] = (uint8_t)(0x80u | dist);
-    } else {
-      P.New.info[pos] = 0x00;
+      ib = (uint8_t)(0x80u | dist);
+    }
+    if (prel < KH_L + KH_SPILL) { skeys[prel] = key; svals[prel] = val; sinfo[prel] = ib; }
+    else {
+      uint64_t pos = (Sc + prel) & mask_n;
+      P.New.keys[pos] = key; P.New.vals[pos] = val; P.New.info[pos] = ib;
     }
   };
   kh_for_each_old<KIND, HASH>(P, c, &s_emin, place);
-  uint64_t nb, ne;
-  kh_new_range(P, c, nb, ne);
-  for (uint64_t i = nb + tid; i < ne; i += KH_CHUNK_THREADS) {
-    uint64_t key = P.ck[i];
-    place(key, P.cv[i], kh_hash64<HASH>(key, P.seed) & mask_n);
+  kh_for_each_new<HASH>(P, c, place);
+  __syncthreads();
+  // stream the slice out
+  long long pend = s_pend;
+  if (pend < (long long)Ln) pend = Ln;
+  // threads with b >= Ln own nothing; when Ln < KH_L the last lane may not be the owner of the last home
+  const uint32_t lo = xr > 0 ? (uint32_t)xr : 0u;
+  uint32_t hi = pend < (long long)(KH_L + KH_SPILL) ? (uint32_t)pend : (KH_L + KH_SPILL);
+  for (uint32_t s0 = lo + tid; s0 < hi; s0 += KH_CHUNK_THREADS) {
+    const uint64_t pos = (Sc + s0) & mask_n;
+    P.New.keys[pos] = skeys[s0];
+    P.New.vals[pos] = svals[s0];
+    P.New.info[pos] = sinfo[s0];
   }
 }
 

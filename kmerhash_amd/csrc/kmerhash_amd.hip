@@ -271,7 +271,7 @@ inline size_t ws_rebuild(uint64_t cap) { return size_t(cap) * 2 + (cap > KH_L ? 
 // Lays out (live elements of t->cur, minus `erased`) U (new distinct elements) at capacity new_cap in
 // a fresh buffer and makes it current.  On KH_ERR_* the current table is unchanged.
 kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint32_t* cv, const uint64_t* noff,
-                  uint32_t PB, const uint32_t* erased, uint64_t total_after) {
+                  const uint32_t* ncnt, uint32_t PB, const uint32_t* erased, uint64_t total_after) {
   if (total_after > new_cap)
     return fail(t, KH_ERR_FULL, "table would hold more elements than buckets (no slot to insert into)");
   KhSlots nw;
@@ -285,7 +285,8 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
   TAKE(flags, uint32_t, KH_NFLAGS);
   HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
   KhRebuildParams P;
-  P.Old = t->cur; P.erased_bits = erased; P.New = nw; P.ck = ck; P.cv = cv; P.noff = noff; P.PB = PB;
+  P.Old = t->cur; P.erased_bits = erased; P.New = nw; P.ck = ck; P.cv = cv; P.noff = noff; P.ncnt = ncnt; P.PB = PB;
+  if (t->lsize == 0) P.Old.cap = 0;   // nothing to carry over: the chunk kernels skip the source scan
   P.seed = t->seed; P.homecnt = homecnt; P.sumA = sumA; P.sumN = sumN; P.xcarry = xcarry; P.flags = flags;
   { Launch L(t, "k_chunk_count");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_count<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, P)); }
@@ -334,7 +335,7 @@ kh_status do_rehash(kh_table* t, uint64_t b) {
     return fail(t, KH_ERR_FULL, "ERROR: did not find any place to insert.  should not have happend (hashmap_linearprobe.hpp:408)");
   }
   { kh_status ps = arena_prepare(t, ws_rebuild(n)); if (ps != KH_OK) return ps; }
-  kh_status st = rebuild(t, n, nullptr, nullptr, nullptr, 0, nullptr, t->lsize);
+  kh_status st = rebuild(t, n, nullptr, nullptr, nullptr, nullptr, 0, nullptr, t->lsize);
   arena_consolidate(t);
   return st;
 }
@@ -345,18 +346,18 @@ kh_status do_reserve(kh_table* t, uint64_t n) {   // :421-426 / :313-318
 
 // ---- radix partition of a batch by bit-reversed chunk id ------------------------------------------
 struct Partitioned {
-  uint64_t* rk; uint32_t* rv; uint32_t* ri;   // records grouped by partition
+  uint64_t* rk; unsigned long long* riv;        // records grouped by partition: key, idx<<32|val
   uint64_t* part_off;                           // [nparts+1]
   uint32_t PB, nparts;
-  uint64_t* spare_k; uint32_t* spare_v; uint32_t* spare_i;   // a second record buffer (free for outputs)
+  uint64_t* spare_k; unsigned long long* spare_iv;   // the other record buffer (free for outputs)
 };
 
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
                           uint64_t n, uint32_t PB, Partitioned& out) {
   const uint32_t nparts = 1u << PB;
-  uint64_t *ak, *bk; uint32_t *av, *ai, *bv, *bi;
-  TAKE(ak, uint64_t, n); TAKE(av, uint32_t, n); TAKE(ai, uint32_t, n);
-  TAKE(bk, uint64_t, n); TAKE(bv, uint32_t, n); TAKE(bi, uint32_t, n);
+  uint64_t *ak, *bk; unsigned long long *aiv, *biv;
+  TAKE(ak, uint64_t, n); TAKE(aiv, unsigned long long, n);
+  TAKE(bk, uint64_t, n); TAKE(biv, unsigned long long, n);
   const uint32_t B1 = PB <= 11 ? PB : (PB + 1) / 2, B2 = PB - B1;
   const uint32_t nb1 = 1u << B1, nb2 = 1u << B2;
   uint32_t* counts1; uint64_t* off1; unsigned long long* cur1;
@@ -364,10 +365,10 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   HIPCHK(hipMemsetAsync(counts1, 0, sizeof(uint32_t) * nb1, t->stream));
   KhPartParams P;
   memset(&P, 0, sizeof(P));
-  P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.idx = nullptr; P.n = n;
+  P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.iv_in = nullptr; P.n = n;
   P.tiles = nullptr; P.ntiles_dev = nullptr; P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
   P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.counts = counts1; P.cursor = cur1;
-  P.ok = ak; P.ov = av; P.oi = ai;
+  P.ok = ak; P.oiv = aiv;
   const uint32_t hist_grid = std::min<uint32_t>(P.ntiles, 1024);
   { Launch L(t, "k_part_hist");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(hist_grid), dim3(KH_PART_THREADS), nb1 * 4, t->stream, P)); }
@@ -377,8 +378,8 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   { Launch L(t, "k_part_scatter");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
   if (B2 == 0) {
-    out.rk = ak; out.rv = av; out.ri = ai; out.part_off = off1; out.PB = PB; out.nparts = nparts;
-    out.spare_k = bk; out.spare_v = bv; out.spare_i = bi;
+    out.rk = ak; out.riv = aiv; out.part_off = off1; out.PB = PB; out.nparts = nparts;
+    out.spare_k = bk; out.spare_iv = biv;
     HIPCHK(hipGetLastError());
     return KH_OK;
   }
@@ -392,9 +393,9 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     hipLaunchKernelGGL(k_make_tiles, dim3(1), dim3(1024), 0, t->stream, off1, nb1, tiles, ntiles_dev); }
   KhPartParams Q = P;
   Q.kbase = reinterpret_cast<const char*>(ak); Q.kstride = 8;
-  Q.vbase = reinterpret_cast<const char*>(av); Q.vstride = 4; Q.idx = ai;
+  Q.vbase = nullptr; Q.vstride = 0; Q.iv_in = aiv;
   Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
-  Q.shift = 0; Q.nb = nb2; Q.counts = counts2; Q.cursor = cur2; Q.ok = bk; Q.ov = bv; Q.oi = bi;
+  Q.shift = 0; Q.nb = nb2; Q.counts = counts2; Q.cursor = cur2; Q.ok = bk; Q.oiv = biv;
   { Launch L(t, "k_part_hist");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); }
   { Launch L(t, "k_scan");
@@ -403,8 +404,8 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   { Launch L(t, "k_part_scatter");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
   HIPCHK(hipGetLastError());
-  out.rk = bk; out.rv = bv; out.ri = bi; out.part_off = off2; out.PB = PB; out.nparts = nparts;
-  out.spare_k = ak; out.spare_v = av; out.spare_i = ai;
+  out.rk = bk; out.riv = biv; out.part_off = off2; out.PB = PB; out.nparts = nparts;
+  out.spare_k = ak; out.spare_iv = aiv;
   return KH_OK;
 }
 
@@ -439,9 +440,9 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   HIPCHK(hipMemsetAsync(scal, 0, sizeof(unsigned long long) * 4, t->stream));
   HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
   KhDedupParams D;
-  D.rk = R.rk; D.rv = R.rv; D.ri = R.ri; D.part_off = R.part_off;
-  D.nk = R.spare_k; D.nv = R.spare_v; D.ni = R.spare_i; D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
-  D.T = t->cur; D.seed = t->seed; D.last_wins = 0; D.flags = flags;
+  D.rk = R.rk; D.riv = R.riv; D.part_off = R.part_off;
+  D.nk = R.spare_k; D.nv = reinterpret_cast<uint32_t*>(R.spare_iv); D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
+  D.T = t->cur; D.seed = t->seed; D.table_empty = t->lsize == 0 ? 1 : 0; D.last_wins = 0; D.flags = flags;
   { Launch L(t, "k_dedup");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
   { Launch L(t, "k_scan");
@@ -457,18 +458,26 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     return fail(t, KH_ERR_HIP, "internal: de-duplication set overflow");
   const uint64_t new_cap = forced_cap ? forced_cap : capacity_after(t, t->cur.cap, t->lsize, n, dnew, last_first);
   if (dnew > 0 || new_cap != t->cur.cap) {
-    uint64_t* ck = nullptr; uint32_t* cv = nullptr;
+    // a chunk of the new table owns 2^(PB-k) consecutive partitions; read their lists in place when that is a
+    // handful, gather them into one dense list when the capacity shrank far below the partitioning capacity
+    const uint32_t k_new = new_cap > KH_L ? log2u(new_cap >> KH_LB) : 0u;
+    const uint64_t* ck = nullptr; const uint32_t* cv = nullptr; const uint64_t* lo = nullptr; const uint32_t* lc = nullptr;
     if (dnew > 0) {
-      TAKE(ck, uint64_t, dnew); TAKE(cv, uint32_t, dnew);
-      Launch L(t, "k_gather_new");
-      hipLaunchKernelGGL(k_gather_new, dim3(R.nparts), dim3(256), 0, t->stream, R.part_off, noff, R.spare_k, R.spare_v, ck, cv);
+      if (PB - k_new <= 3) { ck = D.nk; cv = D.nv; lo = R.part_off; lc = cnt_new; }
+      else {
+        uint64_t* gk; uint32_t* gv;
+        TAKE(gk, uint64_t, dnew); TAKE(gv, uint32_t, dnew);
+        Launch L(t, "k_gather_new");
+        hipLaunchKernelGGL(k_gather_new, dim3(R.nparts), dim3(256), 0, t->stream, R.part_off, noff, D.nk, D.nv, gk, gv);
+        ck = gk; cv = gv; lo = noff; lc = nullptr;
+      }
     }
-    st = rebuild(t, new_cap, ck, cv, dnew > 0 ? noff : nullptr, PB, nullptr, t->lsize + dnew);
+    st = rebuild(t, new_cap, ck, cv, lo, lc, PB, nullptr, t->lsize + dnew);
     if (st != KH_OK) return st;
     t->lsize += dnew;
   }
   if (update) {   // update(k,v): existing keys take the value of their LAST occurrence in the batch
-    D.T = t->cur; D.last_wins = 1;
+    D.T = t->cur; D.table_empty = 0; D.last_wins = 1;
     Launch L(t, "k_dedup_assign");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D));
     HIPCHK(hipGetLastError());
@@ -630,7 +639,7 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
   HIPCHK(hipStreamSynchronize(t->stream));
   const uint64_t ne = t->hpin[0];
   if (ne && t->kind == KHK_RH) {
-    st = rebuild(t, t->cur.cap, nullptr, nullptr, nullptr, 0, bits, t->lsize - ne);
+    st = rebuild(t, t->cur.cap, nullptr, nullptr, nullptr, nullptr, 0, bits, t->lsize - ne);
     if (st != KH_OK) return st;
   }
   t->lsize -= ne;
