@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--keys", type=int, default=KEYS_PER_GPU)
     ap.add_argument("--queries", type=int, default=QUERIES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chunks", type=int, default=4, help="exchange/insert overlap pieces at N>1")
+    ap.add_argument("--chunks", type=int, default=1, help="N>1: pieces of the exchange/insert overlap (1 = exchange, then one bulk insert)")
     args = ap.parse_args()
 
     import torch
@@ -77,7 +77,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("KH_DIST_FORCE_COLLECTIVES", "0") == "1"   # rehearsal of the N>1 path on one GPU
+    if distributed and "RANK" not in os.environ:
+        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

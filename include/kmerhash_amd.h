@@ -85,6 +85,15 @@ kh_status kh_insert_pairs(kh_table* t, const void* pairs16 /*[h|d]*/, uint64_t n
  *      hashmap_robinhood.hpp:1274-1284 / hashmap_linearprobe.hpp:895-905 */
 kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted);
 
+/* ---- reducer insert: the Reducer = std::plus form of the reference's batched table,
+ *      hashmap_robinhood_offsets_reduction::insert(keys, T(1)) / insert(pairs) (robinhood_offset_hashmap_ptr.hpp:85-97,
+ *      2787-2885) as used by dsc::counting_batched_robinhood_map (distributed_batched_robinhood_map.hpp:2542-2543,2633,2899):
+ *      the value of a key becomes the (wrapping 32-bit) sum of the values of all its occurrences; vals == NULL means
+ *      every occurrence contributes 1 (k-mer counting).  Results only are specified by the reference here (its own
+ *      container sizes itself from a HyperLogLog estimate); capacity follows this table's doubling rule. */
+kh_status kh_insert_reduce_plus(kh_table* t, const void* keys /*[h|d] u64[n]*/, const void* vals /*[h|d] u32[n] or NULL*/,
+                                uint64_t n, kh_mem where, uint64_t* n_inserted);
+
 /* ---- count(Iter,Iter): 0/1 per query in query order  hashmap_robinhood.hpp:1111-1160 / hashmap_linearprobe.hpp:639-688
  *      (the reference returns vector<size_t>; one byte per query here) */
 kh_status kh_count(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint8_t* out01 /*[h|d] u8[n]*/);

@@ -250,7 +250,8 @@ struct KhTile { uint64_t beg; uint32_t len; uint32_t seg; };
 
 struct KhPartParams {
   const char* kbase; uint32_t kstride;     // input keys (stride 8 = SoA, 16 = pair array)
-  const char* vbase; uint32_t vstride;     // first pass: input values (may be null: value = 0); iv = position<<32 | value
+  const char* vbase; uint32_t vstride;     // first pass: input values (null: every record carries vconst); iv = position<<32 | value
+  uint32_t vconst;
   const unsigned long long* iv_in;         // later passes: iv of the input records
   uint64_t n;                              // number of input records
   const KhTile* tiles;                     // null: arithmetic tiles of KH_PART_TILE over [0,n), seg 0
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
       key[j] = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
       if (P.iv_in) iv[j] = P.iv_in[d.beg + i];
       else iv[j] = ((unsigned long long)(d.beg + i) << 32) |
-                   (P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : 0u);
+                   (P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : P.vconst);
       uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
       dg[j] = (q >> P.shift) & (nb - 1);
       rk[j] = atomicAdd(&hist[dg[j]], 1u);
@@ -469,10 +470,13 @@ struct KhDedupParams {
   unsigned long long* max_idx_plus1;                             // max (first-occurrence index + 1) over new keys
   KhSlots T; uint64_t seed;
   int table_empty;                                               // size() == 0: skip the membership probes
-  int last_wins;                                                 // 0: insert (first value wins, emit keys the table lacks)
-                                                                 // 1: kh_update assign pass (last value wins, written in place)
+  int mode;                                                      // KH_DEDUP_FIRST : insert (first value wins, emit keys the table lacks)
+                                                                 // KH_DEDUP_LAST  : kh_update assign pass (last value wins, written in place)
+                                                                 // KH_DEDUP_PLUS  : reducer std::plus: values of equal keys are summed; keys the
+                                                                 //                  table holds are increased in place, the others are emitted
   uint32_t* flags;
 };
+enum { KH_DEDUP_FIRST = 0, KH_DEDUP_LAST = 1, KH_DEDUP_PLUS = 2 };
 
 template <int KIND, int HASH>
 __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   const uint64_t beg = P.part_off[q];
   const uint32_t m = (uint32_t)(P.part_off[q + 1] - beg);
   const uint64_t mask = P.T.cap - 1;
-  const unsigned long long iv_init = P.last_wins ? 0ull : ~0ull;
+  const unsigned long long iv_init = P.mode == KH_DEDUP_FIRST ? ~0ull : 0ull;
   if (m == 0) { if (tid == 0) P.cnt_new[q] = 0; return; }
   uint32_t R = (m + KH_HS / 2 - 1) / (KH_HS / 2);   // key classes: at most HS/2 records each on average
   bool done = false;
@@ -506,7 +510,9 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           if (R == 1 || (uint32_t)((f >> 32) % R) == r) {
             if (key == KH_EMPTY_KEY) {
               special_seen = 1;
-              if (P.last_wins) atomicMax(&special_iv, iv); else atomicMin(&special_iv, iv);
+              if (P.mode == KH_DEDUP_FIRST) atomicMin(&special_iv, iv);
+              else if (P.mode == KH_DEDUP_LAST) atomicMax(&special_iv, iv);
+              else atomicAdd(&special_iv, iv & 0xFFFFFFFFull);
             } else {
               uint32_t slot = (uint32_t)f & (KH_HS - 1);
               uint32_t probe = 0;
@@ -517,7 +523,9 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
                   if (cur == KH_EMPTY_KEY) { claimed_slot = (int)slot; cur = key; }
                 }
                 if (cur == key) {
-                  if (P.last_wins) atomicMax(&siv[slot], iv); else atomicMin(&siv[slot], iv);
+                  if (P.mode == KH_DEDUP_FIRST) atomicMin(&siv[slot], iv);
+                  else if (P.mode == KH_DEDUP_LAST) atomicMax(&siv[slot], iv);
+                  else atomicAdd(&siv[slot], iv & 0xFFFFFFFFull);
                   break;
                 }
                 slot = (slot + 1) & (KH_HS - 1);
@@ -546,14 +554,15 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
             const uint64_t h = kh_hash64<HASH>(key, P.seed);
             at = kh_find_pos<KIND>(P.T.keys, P.T.info, mask, h & mask, key);
           }
-          if (P.last_wins) { if (at != KH_NONE) P.T.vals[at] = (uint32_t)iv; }   // kh_update's assign pass: store the LAST value
+          if (P.mode == KH_DEDUP_LAST) { if (at != KH_NONE) P.T.vals[at] = (uint32_t)iv; }   // kh_update's assign pass: store the LAST value
+          else if (P.mode == KH_DEDUP_PLUS && at != KH_NONE) P.T.vals[at] += (uint32_t)iv;       // one lane per distinct key: no race
           else emit = at == KH_NONE;
         }
         const uint32_t pos = kh_wave_append(emit, &out_count);
         if (emit) {
           P.nk[beg + pos] = key;
           P.nv[beg + pos] = (uint32_t)iv;
-          const uint32_t ix = (uint32_t)(iv >> 32) + 1u;
+          const uint32_t ix = P.mode == KH_DEDUP_FIRST ? (uint32_t)(iv >> 32) + 1u : 0u;
           my_max = ix > my_max ? ix : my_max;
         }
       }
@@ -948,5 +957,76 @@ __global__ void k_shard_scatter(const uint64_t* __restrict__ keys, const uint32_
         ++pos;
       }
     }
+  }
+}
+
+// p <= 8 ranks (one node): all per-rank prefix sums in one pass -- the 8 per-lane counters (<= 8 each) travel as
+// 16-bit fields of two 64-bit words through a single wave scan -- and the tile is staged in LDS in (rank, input
+// order) so that the write-out is coalesced.  Stable, like the generic kernel.
+template <int HASH>
+__global__ __launch_bounds__(256) void k_shard_scatter8(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n,
+                                                          uint64_t seed, uint32_t p, uint32_t pmask,
+                                                          const uint64_t* __restrict__ tile_off /* [p][ntiles] exclusive */,
+                                                          uint32_t ntiles, uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
+  __shared__ uint64_t lk[KH_SHARD_TILE];
+  __shared__ uint32_t lv[KH_SHARD_TILE];
+  __shared__ unsigned long long wtot[4][2];
+  __shared__ uint32_t rank_off[9];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint64_t tbase = (uint64_t)blockIdx.x * KH_SHARD_TILE;
+  const uint64_t base = tbase + (uint64_t)tid * 8;
+  const uint32_t tile_len = (n - tbase) < KH_SHARD_TILE ? (uint32_t)(n - tbase) : KH_SHARD_TILE;
+  uint64_t key[8]; uint32_t val[8]; uint32_t rk[8];
+  unsigned long long c0 = 0, c1 = 0;     // counts of ranks 0-3 / 4-7, 16 bits each
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint64_t i = base + j;
+    rk[j] = 0xFFu;
+    if (i < n) {
+      key[j] = keys[i];
+      val[j] = vals ? vals[i] : 0u;
+      rk[j] = kh_rank_of<HASH>(key[j], seed, p, pmask);
+      if (rk[j] < 4) c0 += 1ull << (16 * rk[j]); else c1 += 1ull << (16 * (rk[j] - 4));
+    }
+  }
+  unsigned long long i0 = c0, i1 = c1;
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned long long o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64);
+    if (lane >= (uint32_t)off) { i0 += o0; i1 += o1; }
+  }
+  if (lane == 63) { wtot[wid][0] = i0; wtot[wid][1] = i1; }
+  __syncthreads();
+  unsigned long long e0 = i0 - c0, e1 = i1 - c1, t0 = 0, t1 = 0;
+  for (uint32_t w = 0; w < 4; ++w) {
+    if (w < wid) { e0 += wtot[w][0]; e1 += wtot[w][1]; }
+    t0 += wtot[w][0]; t1 += wtot[w][1];
+  }
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (uint32_t r = 0; r < 8; ++r) {
+      rank_off[r] = run;
+      run += (uint32_t)(((r < 4 ? t0 : t1) >> (16 * (r & 3))) & 0xFFFFu);
+    }
+    rank_off[8] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (rk[j] != 0xFFu) {
+      const uint32_t r = rk[j];
+      const uint32_t within = (uint32_t)(((r < 4 ? e0 : e1) >> (16 * (r & 3))) & 0xFFFFu);
+      const uint32_t s = rank_off[r] + within;
+      lk[s] = key[j]; lv[s] = val[j];
+      if (r < 4) e0 += 1ull << (16 * r); else e1 += 1ull << (16 * (r - 4));
+    }
+  }
+  __syncthreads();
+  for (uint32_t s = tid; s < tile_len; s += 256) {
+    uint32_t r = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 8; ++k) r += (s >= rank_off[k]) ? 1u : 0u;
+    const uint64_t pos = tile_off[(uint64_t)r * ntiles + blockIdx.x] + (s - rank_off[r]);
+    ok[pos] = lk[s];
+    if (vals) ov[pos] = lv[s];
   }
 }

@@ -353,7 +353,7 @@ struct Partitioned {
 };
 
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
-                          uint64_t n, uint32_t PB, Partitioned& out) {
+                          uint32_t vconst, uint64_t n, uint32_t PB, Partitioned& out) {
   const uint32_t nparts = 1u << PB;
   uint64_t *ak, *bk; unsigned long long *aiv, *biv;
   TAKE(ak, uint64_t, n); TAKE(aiv, unsigned long long, n);
@@ -365,7 +365,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   HIPCHK(hipMemsetAsync(counts1, 0, sizeof(uint32_t) * nb1, t->stream));
   KhPartParams P;
   memset(&P, 0, sizeof(P));
-  P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.iv_in = nullptr; P.n = n;
+  P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.iv_in = nullptr; P.n = n;
   P.tiles = nullptr; P.ntiles_dev = nullptr; P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
   P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.counts = counts1; P.cursor = cur1;
   P.ok = ak; P.oiv = aiv;
@@ -423,16 +423,18 @@ uint64_t capacity_after(const kh_table* t, uint64_t cap, uint64_t lsize, uint64_
   return c;
 }
 
+enum { INS_FIRST = 0, INS_UPDATE = 1, INS_PLUS = 2 };
+
 // core of insert/update for one batch of device-resident input (n < 2^32 - 16)
 kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
-                      uint64_t n, bool update, uint64_t forced_cap, uint64_t* n_new_out) {
+                      uint64_t n, int mode, uint64_t forced_cap, uint64_t* n_new_out) {
   *n_new_out = 0;
   if (n == 0) return KH_OK;
   const uint64_t cap_u = forced_cap ? forced_cap : capacity_after(t, t->cur.cap, t->lsize, n, n, n - 1);
   const uint32_t PB = cap_u > KH_L ? log2u(cap_u >> KH_LB) : 0u;
   if (PB > 22) return fail(t, KH_ERR_UNSUPPORTED, "batch would need more than 2^22 partitions");
   Partitioned R;
-  kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, n, PB, R);
+  kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, PB, R);
   if (st != KH_OK) return st;
   uint32_t* cnt_new; uint64_t* noff; unsigned long long* scal; uint32_t* flags;
   TAKE(cnt_new, uint32_t, R.nparts); TAKE(noff, uint64_t, R.nparts + 1); TAKE(scal, unsigned long long, 4);
@@ -442,7 +444,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   KhDedupParams D;
   D.rk = R.rk; D.riv = R.riv; D.part_off = R.part_off;
   D.nk = R.spare_k; D.nv = reinterpret_cast<uint32_t*>(R.spare_iv); D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
-  D.T = t->cur; D.seed = t->seed; D.table_empty = t->lsize == 0 ? 1 : 0; D.last_wins = 0; D.flags = flags;
+  D.T = t->cur; D.seed = t->seed; D.table_empty = t->lsize == 0 ? 1 : 0; D.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST; D.flags = flags;
   { Launch L(t, "k_dedup");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
   { Launch L(t, "k_scan");
@@ -453,7 +455,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   HIPCHK(hipMemcpyAsync(t->hpin + 2, flags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   const uint64_t dnew = t->hpin[0];
-  const uint64_t last_first = t->hpin[1] ? t->hpin[1] - 1 : 0;
+  const uint64_t last_first = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
   if (reinterpret_cast<const uint32_t*>(t->hpin + 2)[KH_FLAG_INTERNAL])
     return fail(t, KH_ERR_HIP, "internal: de-duplication set overflow");
   const uint64_t new_cap = forced_cap ? forced_cap : capacity_after(t, t->cur.cap, t->lsize, n, dnew, last_first);
@@ -476,8 +478,8 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     if (st != KH_OK) return st;
     t->lsize += dnew;
   }
-  if (update) {   // update(k,v): existing keys take the value of their LAST occurrence in the batch
-    D.T = t->cur; D.table_empty = 0; D.last_wins = 1;
+  if (mode == INS_UPDATE) {   // update(k,v): existing keys take the value of their LAST occurrence in the batch
+    D.T = t->cur; D.table_empty = 0; D.mode = KH_DEDUP_LAST;
     Launch L(t, "k_dedup_assign");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D));
     HIPCHK(hipGetLastError());
@@ -487,7 +489,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
 }
 
 kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void* vals, uint32_t vstride, uint64_t n,
-                    kh_mem where, bool update, uint64_t* n_inserted) {
+                    kh_mem where, int mode, uint64_t* n_inserted) {
   if (n_inserted) *n_inserted = 0;
   if (n && !keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
@@ -527,9 +529,9 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
     uint64_t nn = 0;
     if (take == 1 && t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) {
       // single call: exactly one doubling, whatever the load afterwards
-      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, 1, update, t->cur.cap << 1, &nn);
+      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, 1, mode, t->cur.cap << 1, &nn);
     } else {
-      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, take, update, 0, &nn);
+      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, take, mode, 0, &nn);
     }
     total_new += nn;
     done += take;
@@ -741,15 +743,19 @@ kh_status kh_rehash(kh_table* t, uint64_t b) { if (!t) return KH_ERR_INVALID; HI
 
 kh_status kh_insert(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted) {
   if (!t) return KH_ERR_INVALID;
-  return do_insert(t, keys, 8, vals, 4, n, where, false, n_inserted);
+  return do_insert(t, keys, 8, vals, 4, n, where, INS_FIRST, n_inserted);
 }
 kh_status kh_insert_pairs(kh_table* t, const void* pairs16, uint64_t n, kh_mem where, uint64_t* n_inserted) {
   if (!t) return KH_ERR_INVALID;
-  return do_insert(t, pairs16, 16, pairs16 ? static_cast<const char*>(pairs16) + 8 : nullptr, 16, n, where, false, n_inserted);
+  return do_insert(t, pairs16, 16, pairs16 ? static_cast<const char*>(pairs16) + 8 : nullptr, 16, n, where, INS_FIRST, n_inserted);
 }
 kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted) {
   if (!t) return KH_ERR_INVALID;
-  return do_insert(t, keys, 8, vals, 4, n, where, true, n_inserted);
+  return do_insert(t, keys, 8, vals, 4, n, where, INS_UPDATE, n_inserted);
+}
+kh_status kh_insert_reduce_plus(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted) {
+  if (!t) return KH_ERR_INVALID;
+  return do_insert(t, keys, 8, vals, 4, n, where, INS_PLUS, n_inserted);
 }
 
 kh_status kh_count(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint8_t* out01) {
@@ -872,7 +878,7 @@ kh_status kh_hash_batch(kh_hash hash, uint64_t seed, const void* keys, uint64_t 
   const uint64_t* dk = static_cast<const uint64_t*>(keys);
   uint64_t* dout = out; uint64_t* tmp = nullptr;
   if (where == KH_MEM_HOST) {
-    HIPCHK(hipMalloc(&tmp, n * 16));
+    HIPCHK(pool_alloc(device, n * 16, reinterpret_cast<void**>(&tmp)));
     HIPCHK(hipMemcpyAsync(tmp, keys, n * 8, hipMemcpyHostToDevice, stream));
     dk = tmp; dout = tmp + n;
   }
@@ -880,7 +886,7 @@ kh_status kh_hash_batch(kh_hash hash, uint64_t seed, const void* keys, uint64_t 
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && where == KH_MEM_HOST) e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess && where == KH_MEM_HOST) e = hipStreamSynchronize(stream);
-  if (tmp) hipFree(tmp);
+  if (tmp) pool_free(device, tmp);
   return e == hipSuccess ? KH_OK : KH_ERR_HIP;
 }
 
@@ -897,17 +903,21 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64
   const uint32_t pmask = (p & (p - 1)) == 0 ? p - 1 : 0;   // power of two: & (p-1); else % p.  (p == 1: mask 0 -> % 1)
   uint32_t* tc = nullptr; uint64_t* toff = nullptr;
   const uint64_t m = (uint64_t)p * ntiles;
-  HIPCHK(hipMalloc(&tc, m * 4));
-  if (hipMalloc(&toff, (m + 1) * 8) != hipSuccess) { hipFree(tc); return KH_ERR_NOMEM; }
+  HIPCHK(pool_alloc(device, m * 4, reinterpret_cast<void**>(&tc)));
+  if (pool_alloc(device, (m + 1) * 8, reinterpret_cast<void**>(&toff)) != hipSuccess) { pool_free(device, tc); return KH_ERR_NOMEM; }
   KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_count<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, n, seed, p, pmask, tc, ntiles));
   hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, stream, tc, m, toff);
-  KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
+  if (p <= 8) {
+    KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter8<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
+  } else {
+    KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
+  }
   std::vector<uint64_t> ends(p + 1);
   hipError_t e = hipGetLastError();
   for (uint32_t r = 0; r <= p && e == hipSuccess; ++r)
     e = hipMemcpyAsync(&ends[r], toff + (uint64_t)r * ntiles, 8, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  hipFree(tc); hipFree(toff);
+  pool_free(device, tc); pool_free(device, toff);
   if (e != hipSuccess) return KH_ERR_HIP;
   for (uint32_t r = 0; r < p; ++r) counts_host[r] = ends[r + 1] - ends[r];
   return KH_OK;

@@ -23,7 +23,11 @@ except Exception:  # pragma: no cover
     torch = None
     dist = None
 
+import os
+
 DIST_SEED = 9876543   # distributed_batched_robinhood_map.hpp:513-534
+# rehearsal switch: run the collectives even when the group has a single rank (exercises the RCCL path on one GPU)
+FORCE_COLLECTIVES = os.environ.get("KH_DIST_FORCE_COLLECTIVES", "0") == "1"
 
 
 class GpuBackend:
@@ -75,7 +79,7 @@ class ShardedTable:
 
     # ---- exchange helpers ---------------------------------------------------------------------------
     def _exchange_counts(self, send_counts):
-        if self.p == 1:
+        if self.p == 1 and not FORCE_COLLECTIVES:
             return list(send_counts)
         sc = torch.tensor(send_counts, dtype=torch.int64, device=self.b.torch_device)
         rc = torch.empty_like(sc)
@@ -83,7 +87,7 @@ class ShardedTable:
         return [int(x) for x in rc.cpu()]
 
     def _a2av(self, send, send_counts, recv_counts):
-        if self.p == 1:
+        if self.p == 1 and not FORCE_COLLECTIVES:
             return send
         out = self.b.empty(sum(recv_counts), send.dtype)
         dist.all_to_all_single(out, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
@@ -103,7 +107,7 @@ class ShardedTable:
         piece k+1 (comm stream) overlaps the local insert of piece k (compute stream) -- the RCCL analogue of
         khmxx::ialltoallv_and_modify (incremental_mxx.hpp:3437-3645)."""
         n = keys.numel()
-        if chunks <= 1 or self.p == 1 or not keys.is_cuda:
+        if chunks <= 1 or (self.p == 1 and not FORCE_COLLECTIVES) or not keys.is_cuda:
             rk, rv, _, _ = self._route(keys, vals)
             return self.local.insert(rk, rv)
         comm = torch.cuda.Stream(device=self.b.torch_device)
@@ -156,7 +160,7 @@ class ShardedTable:
     def size(self):
         """global size = sum of local sizes"""
         n = self.local.size()
-        if self.p == 1:
+        if self.p == 1 and not FORCE_COLLECTIVES:
             return n
         t = torch.tensor([n], dtype=torch.int64, device=self.b.torch_device)
         dist.all_reduce(t, group=self.group)

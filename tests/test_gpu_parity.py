@@ -239,7 +239,7 @@ def test_sentinel_key_values(oracle):
         g.close()
 
 
-@pytest.mark.parametrize("p", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("p", [1, 2, 3, 4, 5, 8, 16])
 def test_shard_permute_is_stable_partition_by_rank(oracle, p):
     """rank = murmur3(key, seed 9876543) & (p-1) (power of two) or % p; order kept inside a rank"""
     from kmerhash_amd.dist import GpuBackend, DIST_SEED
@@ -265,3 +265,37 @@ def test_sharded_table_single_rank(oracle):
     pk, c = st.count(dev(keys[:1000]))
     assert bool(c.all()) and st.size() == o.size()
     be.table.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_reducer_plus_kmer_counting(kname, cls, kind):
+    """SURVEY §8f-1: Reducer = std::plus (counting_batched_robinhood_map: insert(keys, T(1))): the value of a key is
+    the wrapping 32-bit sum over its occurrences; checked against numpy (the reference semantics is a per-key sum)."""
+    keys, _ = W.w1_benchmark_hashtables(300_000, seed=61)
+    g = cls(128, 0.35, 0.8)
+    uk, cnt = np.unique(keys[:200_000], return_counts=True)
+    assert g.insert_reduce_plus(dev(keys[:200_000])) == len(uk)          # vals=None: every occurrence adds 1
+    sk, sv = g.sorted_items()
+    assert np.array_equal(sk, uk) and np.array_equal(sv, cnt.astype(np.uint32))
+    # second batch: existing keys are increased in place, new ones appended; explicit (wrapping) values
+    k2 = keys[150_000:]
+    v2 = (np.arange(len(k2), dtype=np.uint64) * np.uint64(0x9E3779B1) % np.uint64(2**32)).astype(np.uint32)
+    n_new = g.insert_reduce_plus(k2, v2)
+    exp = dict(zip(uk.tolist(), cnt.astype(np.uint64).tolist()))
+    new = 0
+    for k, v in zip(k2.tolist(), v2.tolist()):
+        if k not in exp:
+            exp[k] = 0
+            new += 1
+        exp[k] = (exp[k] + v) & 0xFFFFFFFF
+    assert n_new == new and g.size() == len(exp)
+    sk, sv = g.sorted_items()
+    ek = np.array(sorted(exp), dtype=np.uint64)
+    assert np.array_equal(sk, ek)
+    assert np.array_equal(sv, np.array([exp[int(k)] for k in ek], dtype=np.uint32))
+    if kind == 0:
+        from_scratch = cls(g.capacity(), 0.35, 0.8)
+        from_scratch.insert(ek, np.zeros(len(ek), dtype=np.uint32))
+        assert np.array_equal(g.export_info(), from_scratch.export_info())   # layout is the canonical one
+        from_scratch.close()
+    g.close()
