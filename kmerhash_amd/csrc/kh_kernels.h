@@ -26,7 +26,7 @@
 #define KH_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
 enum { KHK_RH = 0, KHK_LP = 1 };
-enum { KH_FLAG_PROBE_OVERFLOW = 0, KH_FLAG_REGION_OVERFLOW = 1, KH_FLAG_COUNT_OVERFLOW = 2, KH_FLAG_INTERNAL = 3, KH_NFLAGS = 8 };
+enum { KH_FLAG_PROBE_OVERFLOW = 0, KH_FLAG_REGION_OVERFLOW = 1, KH_FLAG_COUNT_OVERFLOW = 2, KH_FLAG_INTERNAL = 3, KH_FLAG_FUSE_INVALID = 4, KH_NFLAGS = 8 };
 
 // info-byte predicates of the two reference encodings
 template <int KIND> __device__ __forceinline__ bool kh_is_empty(uint32_t b) { return KIND == KHK_RH ? (b == 0x00u) : (b == 0x40u); }
@@ -441,6 +441,44 @@ __global__ void k_make_tiles(const uint64_t* __restrict__ segoff, uint32_t nseg,
 }
 
 
+// (max,+) composite: f(x) = max(A, x + n); combine(first, then) = then o first
+struct KhMP { long long A; long long n; };
+#define KH_MP_NEG (-(1ll << 60))
+__device__ __forceinline__ KhMP kh_mp_combine(KhMP first, KhMP then) {
+  KhMP r;
+  long long a = first.A + then.n;
+  r.A = then.A > a ? then.A : a;
+  r.n = first.n + then.n;
+  return r;
+}
+// exclusive scan of per-thread composites over the workgroup (thread order); also returns the total
+__device__ __forceinline__ KhMP kh_block_scan_mp(KhMP v, KhMP* s_wtot, KhMP* total) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  KhMP incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    KhMP o;
+    o.A = __shfl_up(incl.A, off, 64);
+    o.n = __shfl_up(incl.n, off, 64);
+    if (lane >= (uint32_t)off) incl = kh_mp_combine(o, incl);
+  }
+  KhMP excl;
+  excl.A = __shfl_up(incl.A, 1, 64);
+  excl.n = __shfl_up(incl.n, 1, 64);
+  if (lane == 0) { excl.A = KH_MP_NEG; excl.n = 0; }
+  __syncthreads();
+  if (lane == 63) s_wtot[wid] = incl;
+  __syncthreads();
+  KhMP wpre; wpre.A = KH_MP_NEG; wpre.n = 0;
+  for (uint32_t w = 0; w < wid; ++w) wpre = kh_mp_combine(wpre, s_wtot[w]);
+  if (total) {
+    KhMP t = wpre;
+    for (uint32_t w = wid; w < nw; ++w) t = kh_mp_combine(t, s_wtot[w]);
+    *total = t;
+  }
+  return kh_mp_combine(wpre, excl);
+}
+
+
 // wave-aggregated append: lanes with `want` get consecutive positions from *counter (one LDS atomic per wave)
 __device__ __forceinline__ uint32_t kh_wave_append(bool want, uint32_t* counter) {
   const unsigned long long m = __ballot(want);
@@ -469,6 +507,10 @@ struct KhDedupParams {
   uint32_t* cnt_new;                                             // [nparts]
   unsigned long long* max_idx_plus1;                             // max (first-occurrence index + 1) over new keys
   KhSlots T; uint64_t seed;
+  // speculative fusion of the chunk-count step (empty table, one partition == one chunk of capacity count_cap):
+  // home-bucket counts and the chunk's (max,+) summary are produced here and k_chunk_count is skipped when the
+  // capacity decided after this kernel equals count_cap
+  uint64_t count_cap; uint32_t PB; uint16_t* homecnt; long long* sumA; long long* sumN;
   int table_empty;                                               // size() == 0: skip the membership probes
   int mode;                                                      // KH_DEDUP_FIRST : insert (first value wins, emit keys the table lacks)
                                                                  // KH_DEDUP_LAST  : kh_update assign pass (last value wins, written in place)
@@ -485,17 +527,26 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ uint16_t claimed[KH_HS];           // slots claimed in this round (the distinct keys)
   __shared__ unsigned long long special_iv;     // the key 0xFFFF...F (the set's empty marker) is kept out of band
   __shared__ uint32_t n_claimed, special_seen, out_count, overflow, max_idx;
+  __shared__ uint32_t cnt16[KH_L / 2];          // fused chunk count: two 16-bit home counters per word
+  __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
   const uint32_t tid = threadIdx.x;
   const uint32_t q = blockIdx.x;
   const uint64_t beg = P.part_off[q];
   const uint32_t m = (uint32_t)(P.part_off[q + 1] - beg);
   const uint64_t mask = P.T.cap - 1;
   const unsigned long long iv_init = P.mode == KH_DEDUP_FIRST ? ~0ull : 0ull;
-  if (m == 0) { if (tid == 0) P.cnt_new[q] = 0; return; }
+  const bool fuse = P.count_cap != 0;
+  const uint64_t cmask = P.count_cap - 1;
+  const uint32_t Lc = P.count_cap > KH_L ? KH_L : (uint32_t)P.count_cap;
+  const uint32_t chunk = P.PB ? (__brev(q) >> (32 - P.PB)) : 0u;      // partition id = bit-reversed chunk id
+  const uint64_t Sc = (uint64_t)chunk * Lc;
+  if (m == 0 && !fuse) { if (tid == 0) P.cnt_new[q] = 0; return; }
   uint32_t R = (m + KH_HS / 2 - 1) / (KH_HS / 2);   // key classes: at most HS/2 records each on average
+  if (R == 0) R = 1;
   bool done = false;
   while (!done) {
     if (tid == 0) { out_count = 0; overflow = 0; max_idx = 0; }
+    if (fuse) for (uint32_t i = tid; i < KH_L / 2; i += KH_CHUNK_THREADS) cnt16[i] = 0;
     for (uint32_t r = 0; r < R; ++r) {
       for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) { skey[s] = KH_EMPTY_KEY; siv[s] = iv_init; }
       if (tid == 0) { special_iv = iv_init; special_seen = 0; n_claimed = 0; }
@@ -564,6 +615,10 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           P.nv[beg + pos] = (uint32_t)iv;
           const uint32_t ix = P.mode == KH_DEDUP_FIRST ? (uint32_t)(iv >> 32) + 1u : 0u;
           my_max = ix > my_max ? ix : my_max;
+          if (fuse) {
+            const uint32_t b = (uint32_t)((kh_hash64<HASH>(key, P.seed) & cmask) - Sc);
+            atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1)));
+          }
         }
       }
       my_max = kh_wave_max(my_max);
@@ -576,6 +631,24 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   if (tid == 0) {
     P.cnt_new[q] = out_count;
     if (out_count) atomicMax(P.max_idx_plus1, (unsigned long long)max_idx);
+  }
+  if (fuse) {      // what k_chunk_count would produce for this chunk
+    __syncthreads();
+    if (tid == 0 && out_count > 0xFFFFu) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);   // 16-bit fields could have wrapped
+    KhMP v; v.A = KH_MP_NEG; v.n = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < KH_L / KH_CHUNK_THREADS; ++j) {
+      const uint32_t b = tid * (KH_L / KH_CHUNK_THREADS) + j;
+      if (b < Lc) {
+        const uint32_t cb = (cnt16[b >> 1] >> (16 * (b & 1))) & 0xFFFFu;
+        P.homecnt[Sc + b] = (uint16_t)cb;
+        KhMP h; h.A = (long long)b + cb; h.n = cb;
+        v = kh_mp_combine(v, h);
+      }
+    }
+    KhMP total;
+    kh_block_scan_mp(v, s_wtot, &total);
+    if (tid == 0) { P.sumA[chunk] = (long long)Sc + total.A; P.sumN[chunk] = total.n; }
   }
 }
 
@@ -680,43 +753,6 @@ __device__ __forceinline__ void kh_for_each_new(const KhRebuildParams& P, uint32
       }
     }
   }
-}
-
-// (max,+) composite: f(x) = max(A, x + n); combine(first, then) = then o first
-struct KhMP { long long A; long long n; };
-#define KH_MP_NEG (-(1ll << 60))
-__device__ __forceinline__ KhMP kh_mp_combine(KhMP first, KhMP then) {
-  KhMP r;
-  long long a = first.A + then.n;
-  r.A = then.A > a ? then.A : a;
-  r.n = first.n + then.n;
-  return r;
-}
-// exclusive scan of per-thread composites over the workgroup (thread order); also returns the total
-__device__ __forceinline__ KhMP kh_block_scan_mp(KhMP v, KhMP* s_wtot, KhMP* total) {
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
-  KhMP incl = v;
-  for (int off = 1; off < 64; off <<= 1) {
-    KhMP o;
-    o.A = __shfl_up(incl.A, off, 64);
-    o.n = __shfl_up(incl.n, off, 64);
-    if (lane >= (uint32_t)off) incl = kh_mp_combine(o, incl);
-  }
-  KhMP excl;
-  excl.A = __shfl_up(incl.A, 1, 64);
-  excl.n = __shfl_up(incl.n, 1, 64);
-  if (lane == 0) { excl.A = KH_MP_NEG; excl.n = 0; }
-  __syncthreads();
-  if (lane == 63) s_wtot[wid] = incl;
-  __syncthreads();
-  KhMP wpre; wpre.A = KH_MP_NEG; wpre.n = 0;
-  for (uint32_t w = 0; w < wid; ++w) wpre = kh_mp_combine(wpre, s_wtot[w]);
-  if (total) {
-    KhMP t = wpre;
-    for (uint32_t w = wid; w < nw; ++w) t = kh_mp_combine(t, s_wtot[w]);
-    *total = t;
-  }
-  return kh_mp_combine(wpre, excl);
 }
 
 #define KH_HOMES_PER_THREAD (KH_L / KH_CHUNK_THREADS)

@@ -270,8 +270,10 @@ inline size_t ws_rebuild(uint64_t cap) { return size_t(cap) * 2 + (cap > KH_L ? 
 // ---- chunk rebuild ---------------------------------------------------------------------------------
 // Lays out (live elements of t->cur, minus `erased`) U (new distinct elements) at capacity new_cap in
 // a fresh buffer and makes it current.  On KH_ERR_* the current table is unchanged.
+struct PreCount { uint16_t* homecnt; long long* sumA; long long* sumN; };   // chunk counts already produced by k_dedup
+
 kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint32_t* cv, const uint64_t* noff,
-                  const uint32_t* ncnt, uint32_t PB, const uint32_t* erased, uint64_t total_after) {
+                  const uint32_t* ncnt, uint32_t PB, const uint32_t* erased, uint64_t total_after, const PreCount* pre = nullptr) {
   if (total_after > new_cap)
     return fail(t, KH_ERR_FULL, "table would hold more elements than buckets (no slot to insert into)");
   KhSlots nw;
@@ -279,8 +281,9 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
   if (st != KH_OK) return st;
   const uint32_t nch = new_cap > KH_L ? (uint32_t)(new_cap >> KH_LB) : 1u;
   uint16_t* homecnt; long long *sumA, *sumN, *xcarry; KhMP* ptmp; uint32_t* flags;
-  TAKE(homecnt, uint16_t, new_cap);
-  TAKE(sumA, long long, nch); TAKE(sumN, long long, nch); TAKE(xcarry, long long, nch);
+  if (pre) { homecnt = pre->homecnt; sumA = pre->sumA; sumN = pre->sumN; }
+  else { TAKE(homecnt, uint16_t, new_cap); TAKE(sumA, long long, nch); TAKE(sumN, long long, nch); }
+  TAKE(xcarry, long long, nch);
   TAKE(ptmp, KhMP, nch);
   TAKE(flags, uint32_t, KH_NFLAGS);
   HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
@@ -288,7 +291,7 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
   P.Old = t->cur; P.erased_bits = erased; P.New = nw; P.ck = ck; P.cv = cv; P.noff = noff; P.ncnt = ncnt; P.PB = PB;
   if (t->lsize == 0) P.Old.cap = 0;   // nothing to carry over: the chunk kernels skip the source scan
   P.seed = t->seed; P.homecnt = homecnt; P.sumA = sumA; P.sumN = sumN; P.xcarry = xcarry; P.flags = flags;
-  { Launch L(t, "k_chunk_count");
+  if (!pre) { Launch L(t, "k_chunk_count");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_count<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, P)); }
   { Launch L(t, "k_chunk_carry");
     hipLaunchKernelGGL(k_chunk_carry, dim3(1), dim3(1024), 0, t->stream, sumA, sumN, nch, (long long)new_cap, xcarry, ptmp); }
@@ -444,6 +447,14 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   KhDedupParams D;
   D.rk = R.rk; D.riv = R.riv; D.part_off = R.part_off;
   D.nk = R.spare_k; D.nv = reinterpret_cast<uint32_t*>(R.spare_iv); D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
+  // speculate that the capacity decided below equals cap_u (true whenever the batch holds few duplicates): then the
+  // de-dup kernel already produces the chunk counts and k_chunk_count is skipped
+  PreCount pre; pre.homecnt = nullptr; pre.sumA = nullptr; pre.sumN = nullptr;
+  const bool fuse = t->lsize == 0;
+  if (fuse) {
+    TAKE(pre.homecnt, uint16_t, cap_u); TAKE(pre.sumA, long long, R.nparts); TAKE(pre.sumN, long long, R.nparts);
+  }
+  D.count_cap = fuse ? cap_u : 0; D.PB = PB; D.homecnt = pre.homecnt; D.sumA = pre.sumA; D.sumN = pre.sumN;
   D.T = t->cur; D.seed = t->seed; D.table_empty = t->lsize == 0 ? 1 : 0; D.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST; D.flags = flags;
   { Launch L(t, "k_dedup");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
@@ -474,12 +485,13 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
         ck = gk; cv = gv; lo = noff; lc = nullptr;
       }
     }
-    st = rebuild(t, new_cap, ck, cv, lo, lc, PB, nullptr, t->lsize + dnew);
+    const bool pre_ok = fuse && new_cap == cap_u && !reinterpret_cast<const uint32_t*>(t->hpin + 2)[KH_FLAG_FUSE_INVALID];
+    st = rebuild(t, new_cap, ck, cv, lo, lc, PB, nullptr, t->lsize + dnew, pre_ok ? &pre : nullptr);
     if (st != KH_OK) return st;
     t->lsize += dnew;
   }
   if (mode == INS_UPDATE) {   // update(k,v): existing keys take the value of their LAST occurrence in the batch
-    D.T = t->cur; D.table_empty = 0; D.mode = KH_DEDUP_LAST;
+    D.T = t->cur; D.table_empty = 0; D.mode = KH_DEDUP_LAST; D.count_cap = 0;
     Launch L(t, "k_dedup_assign");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D));
     HIPCHK(hipGetLastError());
@@ -494,7 +506,7 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
   if (n && !keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
   { const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n ? n : 1, n, n ? n - 1 : 0);
-    kh_status ps = arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_rebuild(cu) + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
+    kh_status ps = arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
     if (ps != KH_OK) return ps; }
   const char* kb = static_cast<const char*>(keys);
   const char* vb = static_cast<const char*>(vals);
