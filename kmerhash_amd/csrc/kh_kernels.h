@@ -520,13 +520,16 @@ struct KhDedupParams {
 };
 enum { KH_DEDUP_FIRST = 0, KH_DEDUP_LAST = 1, KH_DEDUP_PLUS = 2 };
 
+// LDS budget 52 KB (3 workgroups per CU): the partition's records are staged in LDS (16 B each) and the hash set
+// holds 32-bit record indices, so a set entry is claimed with one 32-bit CAS and duplicates fold into the claimed
+// record's (idx|val) word with one 64-bit min/max/add.
+#define KH_DD_M 2048u            // records staged per round
 template <int KIND, int HASH>
 __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
-  __shared__ unsigned long long skey[KH_HS];
-  __shared__ unsigned long long siv[KH_HS];
-  __shared__ uint16_t claimed[KH_HS];           // slots claimed in this round (the distinct keys)
-  __shared__ unsigned long long special_iv;     // the key 0xFFFF...F (the set's empty marker) is kept out of band
-  __shared__ uint32_t n_claimed, special_seen, out_count, overflow, max_idx;
+  __shared__ unsigned long long lk[KH_DD_M];
+  __shared__ unsigned long long liv[KH_DD_M];
+  __shared__ uint32_t set[KH_HS];               // 0 = empty, else staged record index + 1 (the key's representative)
+  __shared__ uint32_t n_staged, out_count, overflow, max_idx;
   __shared__ uint32_t cnt16[KH_L / 2];          // fused chunk count: two 16-bit home counters per word
   __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
   const uint32_t tid = threadIdx.x;
@@ -534,72 +537,75 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   const uint64_t beg = P.part_off[q];
   const uint32_t m = (uint32_t)(P.part_off[q + 1] - beg);
   const uint64_t mask = P.T.cap - 1;
-  const unsigned long long iv_init = P.mode == KH_DEDUP_FIRST ? ~0ull : 0ull;
   const bool fuse = P.count_cap != 0;
   const uint64_t cmask = P.count_cap - 1;
   const uint32_t Lc = P.count_cap > KH_L ? KH_L : (uint32_t)P.count_cap;
   const uint32_t chunk = P.PB ? (__brev(q) >> (32 - P.PB)) : 0u;      // partition id = bit-reversed chunk id
   const uint64_t Sc = (uint64_t)chunk * Lc;
   if (m == 0 && !fuse) { if (tid == 0) P.cnt_new[q] = 0; return; }
-  uint32_t R = (m + KH_HS / 2 - 1) / (KH_HS / 2);   // key classes: at most HS/2 records each on average
-  if (R == 0) R = 1;
+  // key classes (by a hash independent of the table's): one round when the partition fits the staging area
+  uint32_t R = m <= KH_DD_M ? 1u : (m + KH_DD_M / 2 - 1) / (KH_DD_M / 2);
   bool done = false;
   while (!done) {
     if (tid == 0) { out_count = 0; overflow = 0; max_idx = 0; }
     if (fuse) for (uint32_t i = tid; i < KH_L / 2; i += KH_CHUNK_THREADS) cnt16[i] = 0;
     for (uint32_t r = 0; r < R; ++r) {
-      for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) { skey[s] = KH_EMPTY_KEY; siv[s] = iv_init; }
-      if (tid == 0) { special_iv = iv_init; special_seen = 0; n_claimed = 0; }
+      for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+      if (tid == 0) n_staged = 0;
       __syncthreads();
-      for (uint32_t i0 = 0; i0 < m; i0 += KH_CHUNK_THREADS) {     // wave-uniform trip count (ballots below)
+      // stage the records of class r
+      for (uint32_t i0 = 0; i0 < m; i0 += KH_CHUNK_THREADS) {
         const uint32_t i = i0 + tid;
-        int claimed_slot = -1;
+        bool take = false;
+        unsigned long long key = 0, iv = 0;
         if (i < m) {
-          const unsigned long long key = P.rk[beg + i];
-          const unsigned long long iv = P.riv[beg + i];
-          const uint64_t f = kh_fmix64(key + 0x9E3779B97F4A7C15ull);
-          if (R == 1 || (uint32_t)((f >> 32) % R) == r) {
-            if (key == KH_EMPTY_KEY) {
-              special_seen = 1;
-              if (P.mode == KH_DEDUP_FIRST) atomicMin(&special_iv, iv);
-              else if (P.mode == KH_DEDUP_LAST) atomicMax(&special_iv, iv);
-              else atomicAdd(&special_iv, iv & 0xFFFFFFFFull);
-            } else {
-              uint32_t slot = (uint32_t)f & (KH_HS - 1);
-              uint32_t probe = 0;
-              for (; probe < KH_HS; ++probe) {
-                unsigned long long cur = skey[slot];
-                if (cur == KH_EMPTY_KEY) {
-                  cur = atomicCAS(&skey[slot], KH_EMPTY_KEY, key);
-                  if (cur == KH_EMPTY_KEY) { claimed_slot = (int)slot; cur = key; }
-                }
-                if (cur == key) {
-                  if (P.mode == KH_DEDUP_FIRST) atomicMin(&siv[slot], iv);
-                  else if (P.mode == KH_DEDUP_LAST) atomicMax(&siv[slot], iv);
-                  else atomicAdd(&siv[slot], iv & 0xFFFFFFFFull);
-                  break;
-                }
-                slot = (slot + 1) & (KH_HS - 1);
-              }
-              if (probe == KH_HS) overflow = 1;
-            }
-          }
+          key = P.rk[beg + i];
+          iv = P.riv[beg + i];
+          take = R == 1 || (uint32_t)((kh_fmix64(key + 0x9E3779B97F4A7C15ull) >> 32) % R) == r;
         }
-        const uint32_t at = kh_wave_append(claimed_slot >= 0, &n_claimed);
-        if (claimed_slot >= 0) claimed[at] = (uint16_t)claimed_slot;
+        uint32_t x = R == 1 ? i : kh_wave_append(take, &n_staged);
+        if (take) {
+          if (x < KH_DD_M) { lk[x] = key; liv[x] = iv; }
+          else overflow = 1;
+        }
       }
       __syncthreads();
       if (overflow) break;
+      const uint32_t ns = R == 1 ? m : n_staged;
+      // fold duplicates into their representative (the record that claimed the set entry)
+      uint32_t rep_mask = 0;          // which of this lane's records are representatives (<= 4 per lane)
+      for (uint32_t x0 = 0, it = 0; x0 < ns; x0 += KH_CHUNK_THREADS, ++it) {
+        const uint32_t x = x0 + tid;
+        if (x < ns) {
+          const unsigned long long key = lk[x];
+          uint32_t slot = (uint32_t)kh_fmix64(key + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
+          for (;;) {     // ns <= KH_DD_M < KH_HS: an empty entry always exists
+            uint32_t cur = set[slot];
+            if (cur == 0) {
+              cur = atomicCAS(&set[slot], 0u, x + 1u);
+              if (cur == 0) { rep_mask |= 1u << it; break; }
+            }
+            const uint32_t rep = cur - 1u;
+            if (lk[rep] == key) {
+              const unsigned long long iv = liv[x];
+              if (P.mode == KH_DEDUP_FIRST) atomicMin(&liv[rep], iv);
+              else if (P.mode == KH_DEDUP_LAST) atomicMax(&liv[rep], iv);
+              else atomicAdd(&liv[rep], iv & 0xFFFFFFFFull);
+              break;
+            }
+            slot = (slot + 1) & (KH_HS - 1);
+          }
+        }
+      }
+      __syncthreads();
       // the distinct keys of this class: test membership in the current table, emit the new ones
-      const uint32_t nd = n_claimed + (special_seen ? 1u : 0u);
       uint32_t my_max = 0;
-      for (uint32_t j0 = 0; j0 < nd; j0 += KH_CHUNK_THREADS) {
-        const uint32_t j = j0 + tid;
+      for (uint32_t x0 = 0, it = 0; x0 < ns; x0 += KH_CHUNK_THREADS, ++it) {
+        const uint32_t x = x0 + tid;
         bool emit = false;
         unsigned long long key = 0, iv = 0;
-        if (j < nd) {
-          if (j < n_claimed) { const uint32_t s = claimed[j]; key = skey[s]; iv = siv[s]; }
-          else { key = KH_EMPTY_KEY; iv = special_iv; }
+        if (x < ns && ((rep_mask >> it) & 1u)) {
+          key = lk[x]; iv = liv[x];
           uint64_t at = KH_NONE;
           if (!P.table_empty) {
             const uint64_t h = kh_hash64<HASH>(key, P.seed);
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
       if ((tid & 63) == 0 && my_max) atomicMax(&max_idx, my_max);
       __syncthreads();
     }
-    if (overflow) { R *= 2; __syncthreads(); if (R > m) { if (tid == 0) atomicOr(&P.flags[KH_FLAG_INTERNAL], 1u); break; } }
+    if (overflow) { R *= 2; __syncthreads(); if (R > 2 * m + 2) { if (tid == 0) atomicOr(&P.flags[KH_FLAG_INTERNAL], 1u); break; } }
     else done = true;
   }
   if (tid == 0) {
