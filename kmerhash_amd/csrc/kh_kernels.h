@@ -252,7 +252,7 @@ struct KhPartParams {
   const char* kbase; uint32_t kstride;     // input keys (stride 8 = SoA, 16 = pair array)
   const char* vbase; uint32_t vstride;     // first pass: input values (null: every record carries vconst); iv = position<<32 | value
   uint32_t vconst;
-  const unsigned long long* iv_in;         // later passes: iv of the input records
+  const ulonglong2* rec_in;                // later passes: the input records (key, iv); kbase/vbase unused
   uint64_t n;                              // number of input records
   const KhTile* tiles;                     // null: arithmetic tiles of KH_PART_TILE over [0,n), seg 0
   const uint32_t* ntiles_dev;              // with tiles: actual tile count
@@ -263,7 +263,7 @@ struct KhPartParams {
   uint32_t nb;                             // bins in this pass (power of two, <= 2048)
   uint32_t* counts;                        // [nseg*nb] histogram (hist kernel)
   unsigned long long* cursor;              // [nseg*nb] running output offsets (scatter kernel)
-  uint64_t* ok; unsigned long long* oiv;   // output records
+  ulonglong2* orec;                        // output records: 16-byte (key, iv) pairs, one dwordx4 access each
 };
 
 // partition id of a hash: chunk id at the partitioning capacity, bit-reversed so that the
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_hist(KhPartParams P) {
       cur_seg = d.seg;
     }
     for (uint32_t i = tid; i < d.len; i += KH_PART_THREADS) {
-      uint64_t key = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
+      uint64_t key = P.rec_in ? P.rec_in[d.beg + i].x : *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
       uint32_t q = kh_part_q(kh_hash64<HASH>(key, P.seed), P.PB);
       atomicAdd(&hist[(q >> P.shift) & (nb - 1)], 1u);
     }
@@ -331,8 +331,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_hist(KhPartParams P) {
 template <int HASH>
 __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P) {
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
-  __shared__ uint64_t lk[KH_PART_TILE];
-  __shared__ unsigned long long liv[KH_PART_TILE];
+  __shared__ ulonglong2 lrec[KH_PART_TILE];
   __shared__ uint16_t ld[KH_PART_TILE];
   __shared__ uint32_t wtot[KH_PART_THREADS / 64];
   const uint32_t nb = P.nb;
@@ -352,10 +351,12 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
   for (int j = 0; j < KH_PART_ITEMS; ++j) {
     uint32_t i = tid + j * KH_PART_THREADS;
     if (i < d.len) {
-      key[j] = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
-      if (P.iv_in) iv[j] = P.iv_in[d.beg + i];
-      else iv[j] = ((unsigned long long)(d.beg + i) << 32) |
-                   (P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : P.vconst);
+      if (P.rec_in) { const ulonglong2 rr = P.rec_in[d.beg + i]; key[j] = rr.x; iv[j] = rr.y; }
+      else {
+        key[j] = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
+        iv[j] = ((unsigned long long)(d.beg + i) << 32) |
+                (P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : P.vconst);
+      }
       uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
       dg[j] = (q >> P.shift) & (nb - 1);
       rk[j] = atomicAdd(&hist[dg[j]], 1u);
@@ -390,15 +391,14 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
     uint32_t i = tid + j * KH_PART_THREADS;
     if (i < d.len) {
       uint32_t s = loff[dg[j]] + rk[j];
-      lk[s] = key[j]; liv[s] = iv[j]; ld[s] = (uint16_t)dg[j];
+      lrec[s] = make_ulonglong2(key[j], iv[j]); ld[s] = (uint16_t)dg[j];
     }
   }
   __syncthreads();
   for (uint32_t s = tid; s < d.len; s += KH_PART_THREADS) {
     uint32_t dd = ld[s];
     uint64_t pos = gbase[dd] + (s - loff[dd]);
-    P.ok[pos] = lk[s];
-    P.oiv[pos] = liv[s];
+    P.orec[pos] = lrec[s];
   }
 }
 
@@ -501,7 +501,7 @@ __device__ __forceinline__ uint32_t kh_wave_max(uint32_t v) {
 // Emits the batch's DISTINCT NEW keys (with the value of their first occurrence).
 // ---------------------------------------------------------------------------------------------
 struct KhDedupParams {
-  const uint64_t* rk; const unsigned long long* riv;            // partitioned records (key, idx<<32|val)
+  const ulonglong2* rec;                                         // partitioned records (key, idx<<32|val)
   const uint64_t* part_off;                                      // [nparts+1]
   uint64_t* nk; uint32_t* nv;                                    // outputs, written at part_off[q] + j
   uint32_t* cnt_new;                                             // [nparts]
@@ -559,8 +559,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
         bool take = false;
         unsigned long long key = 0, iv = 0;
         if (i < m) {
-          key = P.rk[beg + i];
-          iv = P.riv[beg + i];
+          const ulonglong2 rr = P.rec[beg + i];
+          key = rr.x; iv = rr.y;
           take = R == 1 || (uint32_t)((kh_fmix64(key + 0x9E3779B97F4A7C15ull) >> 32) % R) == r;
         }
         uint32_t x = R == 1 ? i : kh_wave_append(take, &n_staged);

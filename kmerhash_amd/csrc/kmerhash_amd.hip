@@ -349,18 +349,17 @@ kh_status do_reserve(kh_table* t, uint64_t n) {   // :421-426 / :313-318
 
 // ---- radix partition of a batch by bit-reversed chunk id ------------------------------------------
 struct Partitioned {
-  uint64_t* rk; unsigned long long* riv;        // records grouped by partition: key, idx<<32|val
+  ulonglong2* rec;                              // records grouped by partition: (key, idx<<32|val)
   uint64_t* part_off;                           // [nparts+1]
   uint32_t PB, nparts;
-  uint64_t* spare_k; unsigned long long* spare_iv;   // the other record buffer (free for outputs)
+  ulonglong2* spare;                            // the other record buffer (free for outputs)
 };
 
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
                           uint32_t vconst, uint64_t n, uint32_t PB, Partitioned& out) {
   const uint32_t nparts = 1u << PB;
-  uint64_t *ak, *bk; unsigned long long *aiv, *biv;
-  TAKE(ak, uint64_t, n); TAKE(aiv, unsigned long long, n);
-  TAKE(bk, uint64_t, n); TAKE(biv, unsigned long long, n);
+  ulonglong2 *ar, *br;
+  TAKE(ar, ulonglong2, n); TAKE(br, ulonglong2, n);
   const uint32_t B1 = PB <= 11 ? PB : (PB + 1) / 2, B2 = PB - B1;
   const uint32_t nb1 = 1u << B1, nb2 = 1u << B2;
   uint32_t* counts1; uint64_t* off1; unsigned long long* cur1;
@@ -368,10 +367,10 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   HIPCHK(hipMemsetAsync(counts1, 0, sizeof(uint32_t) * nb1, t->stream));
   KhPartParams P;
   memset(&P, 0, sizeof(P));
-  P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.iv_in = nullptr; P.n = n;
+  P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.rec_in = nullptr; P.n = n;
   P.tiles = nullptr; P.ntiles_dev = nullptr; P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
   P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.counts = counts1; P.cursor = cur1;
-  P.ok = ak; P.oiv = aiv;
+  P.orec = ar;
   const uint32_t hist_grid = std::min<uint32_t>(P.ntiles, 1024);
   { Launch L(t, "k_part_hist");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(hist_grid), dim3(KH_PART_THREADS), nb1 * 4, t->stream, P)); }
@@ -381,8 +380,8 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   { Launch L(t, "k_part_scatter");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
   if (B2 == 0) {
-    out.rk = ak; out.riv = aiv; out.part_off = off1; out.PB = PB; out.nparts = nparts;
-    out.spare_k = bk; out.spare_iv = biv;
+    out.rec = ar; out.part_off = off1; out.PB = PB; out.nparts = nparts;
+    out.spare = br;
     HIPCHK(hipGetLastError());
     return KH_OK;
   }
@@ -395,10 +394,10 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   { Launch L(t, "k_make_tiles");
     hipLaunchKernelGGL(k_make_tiles, dim3(1), dim3(1024), 0, t->stream, off1, nb1, tiles, ntiles_dev); }
   KhPartParams Q = P;
-  Q.kbase = reinterpret_cast<const char*>(ak); Q.kstride = 8;
-  Q.vbase = nullptr; Q.vstride = 0; Q.iv_in = aiv;
+  Q.kbase = nullptr; Q.kstride = 0;
+  Q.vbase = nullptr; Q.vstride = 0; Q.rec_in = ar;
   Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
-  Q.shift = 0; Q.nb = nb2; Q.counts = counts2; Q.cursor = cur2; Q.ok = bk; Q.oiv = biv;
+  Q.shift = 0; Q.nb = nb2; Q.counts = counts2; Q.cursor = cur2; Q.orec = br;
   { Launch L(t, "k_part_hist");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); }
   { Launch L(t, "k_scan");
@@ -407,8 +406,8 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   { Launch L(t, "k_part_scatter");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
   HIPCHK(hipGetLastError());
-  out.rk = bk; out.riv = biv; out.part_off = off2; out.PB = PB; out.nparts = nparts;
-  out.spare_k = ak; out.spare_iv = aiv;
+  out.rec = br; out.part_off = off2; out.PB = PB; out.nparts = nparts;
+  out.spare = ar;
   return KH_OK;
 }
 
@@ -445,8 +444,10 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   HIPCHK(hipMemsetAsync(scal, 0, sizeof(unsigned long long) * 4, t->stream));
   HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
   KhDedupParams D;
-  D.rk = R.rk; D.riv = R.riv; D.part_off = R.part_off;
-  D.nk = R.spare_k; D.nv = reinterpret_cast<uint32_t*>(R.spare_iv); D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
+  D.rec = R.rec; D.part_off = R.part_off;
+  // outputs go into the other record buffer (16 B per input record): keys in its first half, values behind them
+  D.nk = reinterpret_cast<uint64_t*>(R.spare); D.nv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(R.spare) + n * 8);
+  D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
   // speculate that the capacity decided below equals cap_u (true whenever the batch holds few duplicates): then the
   // de-dup kernel already produces the chunk counts and k_chunk_count is skipped
   PreCount pre; pre.homecnt = nullptr; pre.sumA = nullptr; pre.sumN = nullptr;
