@@ -176,6 +176,18 @@ def main():
         per_launch_ms = total_ms / launches
         units = {"k_find": args.queries, "k_count": args.queries}.get(dom, args.keys)
         bpu = {"k_find": B_FIND_HIT}.get(dom, B_INSERT_NEW)
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this same command
+        # (profiles/<tag>_pmc_hbm_traffic.json, FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md
+        # prescribes); PMC counters cannot be read from inside the timed process, so this is the recorded figure
+        traffic = None
+        try:
+            import glob
+            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+            if pj and not distributed:
+                traffic = json.load(open(pj[-1])).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_src = os.path.basename(pj[-1])
+        except Exception:
+            traffic = None
         launches_per_step = launches / args.steps
         alg_bytes = units * bpu / max(launches_per_step, 1.0)          # algorithmic bytes one launch accounts for
         achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
@@ -195,7 +207,8 @@ def main():
             "inserts_per_s": ins_rate, "finds_per_s": find_rate,
             "insert_ms": float(np.mean(ins_ms)), "find_ms": float(np.mean(find_ms)),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (traffic_src if traffic else None),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms,
                          "whole_insert_path_frac": ins_rate / world * B_INSERT_NEW / 1e9 / HBM_PEAK_GBS,
                          "whole_find_path_frac": find_rate / world * B_FIND_HIT / 1e9 / HBM_PEAK_GBS},

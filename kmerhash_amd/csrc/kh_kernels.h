@@ -157,11 +157,14 @@ __global__ void k_assign_existing(KhSlots T, const uint64_t* __restrict__ q, con
 #define KH_CMP_TILE 2048
 __global__ void k_flag_tile_sums(const uint8_t* __restrict__ flags, uint64_t n, uint32_t* __restrict__ sums) {
   __shared__ uint32_t wsum[4];
-  uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE;
+  const uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE + (uint64_t)threadIdx.x * 8;
   uint32_t c = 0;
-  for (uint32_t j = threadIdx.x; j < KH_CMP_TILE; j += 256) {
-    uint64_t i = base + j;
-    if (i < n && flags[i]) ++c;
+  if (base + 8 <= n) {
+    const uint64_t fw = *reinterpret_cast<const uint64_t*>(flags + base);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c += ((fw >> (8 * j)) & 0xFFu) ? 1u : 0u;
+  } else {
+    for (int j = 0; j < 8; ++j) if (base + j < n && flags[base + j]) ++c;
   }
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -204,18 +207,23 @@ __global__ void k_scan_u32_to_u64(const uint32_t* __restrict__ in, uint64_t n, u
   if (tid == 0) out[n] = carry_s;
 }
 
-__global__ void k_compact_hits(const uint8_t* __restrict__ flags, const uint64_t* __restrict__ q, const uint32_t* __restrict__ vals,
+__global__ __launch_bounds__(256) void k_compact_hits(const uint8_t* __restrict__ flags, const uint64_t* __restrict__ q, const uint32_t* __restrict__ vals,
                                uint64_t n, const uint64_t* __restrict__ tile_off,
                                uint64_t* __restrict__ out_keys, uint32_t* __restrict__ out_vals, uint8_t* __restrict__ out_pairs16) {
-  // one 256-thread workgroup per KH_CMP_TILE queries; each lane owns 8 consecutive queries so that
-  // the hit order inside the tile is the query order.
+  // one 256-thread workgroup per KH_CMP_TILE queries; each lane owns 8 consecutive queries (one 8-byte flag word),
+  // so the hit order inside the tile is the query order; hits are staged in LDS and streamed out coalesced.
+  __shared__ uint64_t lk[KH_CMP_TILE];
+  __shared__ uint32_t lv[KH_CMP_TILE];
   __shared__ uint32_t wtot[4];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE + (uint64_t)tid * 8;
+  const uint64_t tbase = (uint64_t)blockIdx.x * KH_CMP_TILE;
+  const uint64_t base = tbase + (uint64_t)tid * 8;
+  uint64_t fw = 0;
+  if (base + 8 <= n) fw = *reinterpret_cast<const uint64_t*>(flags + base);     // flags buffer is 256-byte aligned, base % 8 == 0
+  else for (int j = 0; j < 8; ++j) if (base + j < n && flags[base + j]) fw |= 1ull << (8 * j);
   uint32_t c = 0;
-  uint8_t f[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { uint64_t i = base + j; f[j] = (i < n) ? flags[i] : 0; c += f[j] ? 1 : 0; }
+  for (int j = 0; j < 8; ++j) c += ((fw >> (8 * j)) & 0xFFu) ? 1u : 0u;
   uint32_t incl = c;
   for (int off = 1; off < 64; off <<= 1) {
     uint32_t o = __shfl_up(incl, off, 64);
@@ -223,22 +231,23 @@ __global__ void k_compact_hits(const uint8_t* __restrict__ flags, const uint64_t
   }
   if (lane == 63) wtot[wid] = incl;
   __syncthreads();
-  uint32_t wpre = 0;
-  for (uint32_t w = 0; w < wid; ++w) wpre += wtot[w];
-  uint64_t pos = tile_off[blockIdx.x] + wpre + incl - c;
+  uint32_t wpre = 0, total = 0;
+  for (uint32_t w = 0; w < 4; ++w) { if (w < wid) wpre += wtot[w]; total += wtot[w]; }
+  uint32_t x = wpre + incl - c;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (f[j]) {
-      uint64_t i = base + j;
-      if (out_pairs16) {
-        *reinterpret_cast<uint64_t*>(out_pairs16 + pos * 16) = q[i];
-        *reinterpret_cast<uint32_t*>(out_pairs16 + pos * 16 + 8) = vals[i];
-        *reinterpret_cast<uint32_t*>(out_pairs16 + pos * 16 + 12) = 0;
-      } else {
-        out_keys[pos] = q[i];
-        out_vals[pos] = vals[i];
-      }
-      ++pos;
+    if ((fw >> (8 * j)) & 0xFFu) { lk[x] = q[base + j]; lv[x] = vals[base + j]; ++x; }
+  }
+  __syncthreads();
+  const uint64_t obase = tile_off[blockIdx.x];
+  for (uint32_t s = tid; s < total; s += 256) {
+    if (out_pairs16) {
+      uint4 w;
+      w.x = (uint32_t)lk[s]; w.y = (uint32_t)(lk[s] >> 32); w.z = lv[s]; w.w = 0;
+      *reinterpret_cast<uint4*>(out_pairs16 + (obase + s) * 16) = w;
+    } else {
+      out_keys[obase + s] = lk[s];
+      out_vals[obase + s] = lv[s];
     }
   }
 }
