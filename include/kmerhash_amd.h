@@ -131,6 +131,21 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t nranks,
                            uint64_t* out_keys_dev, uint32_t* out_vals_dev /* may be NULL */,
                            uint64_t* counts_host, int device, void* hip_stream);
 
+/* ---- HyperLogLog cardinality estimator: fsc::hyperloglog64<T, Hash, precision> (hyperloglog64.hpp:142-475),
+ *      64-bit hash values: register = top `precision` bits after dropping `ignore_msb` bits, rank = leading zeros + 1
+ *      (:175-188); estimate() = harmonic mean with the linear-counting branch below 5m/2 (:201-236).  Registers are
+ *      bit-exact with the reference; the estimate is computed on the host in the reference's operation order. */
+typedef struct kh_hll kh_hll;
+kh_status kh_hll_create(kh_hll** out, uint32_t precision /*12*/, uint32_t ignore_msb /*0*/, kh_hash hash, uint64_t seed, int device);
+kh_status kh_hll_destroy(kh_hll* h);
+kh_status kh_hll_set_stream(kh_hll* h, void* hip_stream);
+kh_status kh_hll_update(kh_hll* h, const void* keys /*[h|d] u64[n]*/, uint64_t n, kh_mem where);               /* update(vals,count) :357 */
+kh_status kh_hll_update_via_hashval(kh_hll* h, const void* hashes /*[h|d] u64[n]*/, uint64_t n, kh_mem where); /* :449-455 */
+kh_status kh_hll_merge(kh_hll* h, const kh_hll* other);   /* :463 */
+kh_status kh_hll_clear(kh_hll* h);                        /* :467 */
+kh_status kh_hll_registers(kh_hll* h, uint8_t* out_host /* 2^precision bytes */);
+kh_status kh_hll_estimate(kh_hll* h, double* out);       /* :459 */
+
 /* ---- measurement hooks: per-kernel HIP-event timing on the table's stream (bench.py roofline) */
 kh_status kh_profile_enable(kh_table* t, int on);
 kh_status kh_profile_reset(kh_table* t);

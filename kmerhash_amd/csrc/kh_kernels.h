@@ -1081,3 +1081,39 @@ __global__ __launch_bounds__(256) void k_shard_scatter8(const uint64_t* __restri
     if (vals) ov[pos] = lv[s];
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// HyperLogLog register update (reference hyperloglog64.hpp:175-188 internal_update):
+//   v = hash << ignored_msb ; register index = top `precision` bits of v ; rank = clz((v << precision) | mask) + 1
+//   with mask = low (precision + ignored_msb) bits set ; register = max(register, rank).
+// Registers are accumulated per workgroup in LDS (precision <= 13) and merged with global atomicMax.
+// ---------------------------------------------------------------------------------------------
+template <int HASH, bool FROM_KEYS>
+__global__ void k_hll_update(const uint64_t* __restrict__ in, uint64_t n, uint64_t seed, uint32_t precision, uint32_t ignored,
+                             uint32_t* __restrict__ regs, int use_lds) {
+  extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
+  const uint32_t m = 1u << precision;
+  if (use_lds) {
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) kh_dyn_smem[i] = 0;
+    __syncthreads();
+  }
+  const uint64_t lzc_mask = ~0ull >> (64 - precision - ignored);
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const uint64_t hv = FROM_KEYS ? kh_hash64<HASH>(in[i], seed) : in[i];
+    const uint64_t v = hv << ignored;
+    const uint32_t r = (uint32_t)(v >> (64 - precision));
+    const uint32_t rank = (uint32_t)__clzll((long long)((v << precision) | lzc_mask)) + 1u;
+    if (use_lds) atomicMax(&kh_dyn_smem[r], rank); else atomicMax(&regs[r], rank);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < m; j += blockDim.x) { const uint32_t v = kh_dyn_smem[j]; if (v) atomicMax(&regs[j], v); }
+  }
+}
+__global__ void k_hll_merge(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t m) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) { const uint32_t a = dst[i], b = src[i]; dst[i] = a > b ? a : b; }
+}
+

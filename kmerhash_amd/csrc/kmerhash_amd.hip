@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <cmath>
 
 #include <map>
 #include <mutex>
@@ -933,6 +934,117 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64
   pool_free(device, tc); pool_free(device, toff);
   if (e != hipSuccess) return KH_ERR_HIP;
   for (uint32_t r = 0; r < p; ++r) counts_host[r] = ends[r + 1] - ends[r];
+  return KH_OK;
+}
+
+// ---- HyperLogLog (hyperloglog64.hpp) --------------------------------------------------------------
+}  // extern "C"
+struct kh_hll {
+  int device, hash; uint64_t seed; uint32_t precision, ignored; uint32_t* regs; hipStream_t stream;
+};
+extern "C" {
+kh_status kh_hll_create(kh_hll** out, uint32_t precision, uint32_t ignore_msb, kh_hash hash, uint64_t seed, int device) {
+  kh_table* t = nullptr;
+  if (!out) return KH_ERR_INVALID;
+  *out = nullptr;
+  if (precision < 4 || precision > 18 || precision + ignore_msb >= 64 || (int)hash < 0 || (int)hash > 3) return KH_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return KH_ERR_HIP;
+  HIPCHK(hipSetDevice(device));
+  kh_hll* h = new kh_hll();
+  h->device = device; h->hash = (int)hash; h->seed = seed; h->precision = precision; h->ignored = ignore_msb; h->stream = nullptr; h->regs = nullptr;
+  if (pool_alloc(device, sizeof(uint32_t) << precision, reinterpret_cast<void**>(&h->regs)) != hipSuccess) { delete h; return KH_ERR_NOMEM; }
+  if (hipMemset(h->regs, 0, sizeof(uint32_t) << precision) != hipSuccess) { pool_free(device, h->regs); delete h; return KH_ERR_HIP; }
+  *out = h;
+  return KH_OK;
+}
+kh_status kh_hll_destroy(kh_hll* h) {
+  if (!h) return KH_OK;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  pool_free(h->device, h->regs);
+  delete h;
+  return KH_OK;
+}
+kh_status kh_hll_set_stream(kh_hll* h, void* s) { if (!h) return KH_ERR_INVALID; h->stream = static_cast<hipStream_t>(s); return KH_OK; }
+static kh_status hll_update(kh_hll* h, const void* in, uint64_t n, kh_mem where, bool from_keys) {
+  kh_table* t = nullptr;
+  if (!h) return KH_ERR_INVALID;
+  if (n == 0) return KH_OK;
+  if (!in) return KH_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  const uint64_t* d = static_cast<const uint64_t*>(in);
+  uint64_t* tmp = nullptr;
+  if (where == KH_MEM_HOST) {
+    HIPCHK(pool_alloc(h->device, n * 8, reinterpret_cast<void**>(&tmp)));
+    hipError_t e = hipMemcpyAsync(tmp, in, n * 8, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) { pool_free(h->device, tmp); return KH_ERR_HIP; }
+    d = tmp;
+  }
+  const int use_lds = h->precision <= 13 ? 1 : 0;
+  const size_t smem = use_lds ? (sizeof(uint32_t) << h->precision) : 0;
+  const uint32_t grid = grid_for(n, 256, 1024);
+  if (from_keys) {
+    KH_SWITCH_HASH(h->hash, hipLaunchKernelGGL((k_hll_update<HASH, true>), dim3(grid), dim3(256), smem, h->stream, d, n, h->seed, h->precision, h->ignored, h->regs, use_lds));
+  } else {
+    hipLaunchKernelGGL((k_hll_update<KHH_IDENTITY, false>), dim3(grid), dim3(256), smem, h->stream, d, n, h->seed, h->precision, h->ignored, h->regs, use_lds);
+  }
+  hipError_t e = hipGetLastError();
+  if (tmp) { if (e == hipSuccess) e = hipStreamSynchronize(h->stream); pool_free(h->device, tmp); }
+  return e == hipSuccess ? KH_OK : KH_ERR_HIP;
+}
+kh_status kh_hll_update(kh_hll* h, const void* keys, uint64_t n, kh_mem where) { return hll_update(h, keys, n, where, true); }
+kh_status kh_hll_update_via_hashval(kh_hll* h, const void* hashes, uint64_t n, kh_mem where) { return hll_update(h, hashes, n, where, false); }
+kh_status kh_hll_merge(kh_hll* h, const kh_hll* other) {
+  kh_table* t = nullptr;
+  if (!h || !other || h->precision != other->precision || h->device != other->device) return KH_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  const uint32_t m = 1u << h->precision;
+  hipLaunchKernelGGL(k_hll_merge, dim3((m + 255) / 256), dim3(256), 0, h->stream, h->regs, other->regs, m);
+  HIPCHK(hipGetLastError());
+  return KH_OK;
+}
+kh_status kh_hll_clear(kh_hll* h) {
+  kh_table* t = nullptr;
+  if (!h) return KH_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipMemsetAsync(h->regs, 0, sizeof(uint32_t) << h->precision, h->stream));
+  return KH_OK;
+}
+kh_status kh_hll_registers(kh_hll* h, uint8_t* out_host) {
+  kh_table* t = nullptr;
+  if (!h || !out_host) return KH_ERR_INVALID;
+  HIPCHK(hipSetDevice(h->device));
+  const uint32_t m = 1u << h->precision;
+  std::vector<uint32_t> r(m);
+  HIPCHK(hipMemcpyAsync(r.data(), h->regs, sizeof(uint32_t) * m, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (uint32_t i = 0; i < m; ++i) out_host[i] = (uint8_t)r[i];
+  return KH_OK;
+}
+// internal_estimate (hyperloglog64.hpp:201-236): same operation order in double, so equal registers give an equal double
+kh_status kh_hll_estimate(kh_hll* h, double* out) {
+  if (!h || !out) return KH_ERR_INVALID;
+  const uint32_t m = 1u << h->precision;
+  std::vector<uint8_t> regs(m);
+  kh_status st = kh_hll_registers(h, regs.data());
+  if (st != KH_OK) return st;
+  double amm;
+  switch (h->precision) {
+    case 4: amm = 0.673; break;
+    case 5: amm = 0.697; break;
+    case 6: amm = 0.709; break;
+    default: amm = 0.7213 / (1.0 + (1.079 / static_cast<double>(m))); break;
+  }
+  amm *= static_cast<double>(0x1ULL << (h->precision << 1U));
+  double sum = 0.0;
+  uint32_t zeros = 0;
+  for (uint32_t i = 0; i < m; ++i) { sum += 1.0 / static_cast<double>(1ULL << regs[i]); if (regs[i] == 0) ++zeros; }
+  double est = amm / sum;
+  if (est <= static_cast<double>(5ULL * (m >> 1ULL))) {
+    if (zeros > 0) est = static_cast<double>(m) * std::log(static_cast<double>(m) / static_cast<double>(zeros));
+  }
+  *out = est;
   return KH_OK;
 }
 

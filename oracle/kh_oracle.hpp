@@ -38,6 +38,8 @@
 #include <utility>
 #include <stdexcept>
 #include <limits>
+#include <cmath>
+#include <algorithm>
 
 namespace kh_oracle {
 
@@ -502,6 +504,55 @@ class LinearProbe {
     for (size_t i = 0; i < n; ++i) erased += erase_no_resize(keys[i]);
     if (lsize < min_load) rehash(static_cast<size_t>(static_cast<float>(lsize) / max_load_factor));
     return erased;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// HyperLogLog, 64-bit hash values (hyperloglog64.hpp).  PINNED: the reference header compiles from the reference tree
+// as it lies (oracle/_ref/libref_hll.so); tests compare registers and estimates with it.
+// ---------------------------------------------------------------------------------------------
+class HyperLogLog64 {
+ public:
+  uint32_t precision, ignored_msb, nreg;
+  int hash_id; uint64_t seed;
+  std::vector<uint8_t> registers;
+  double amm;
+  uint64_t lzc_mask;
+  // ctor :264-296
+  HyperLogLog64(uint32_t p, uint32_t ignore_msb, int hid, uint64_t sd)
+      : precision(p), ignored_msb(ignore_msb), nreg(1u << p), hash_id(hid), seed(sd), registers(1u << p, 0) {
+    lzc_mask = ~uint64_t(0) >> (64 - precision - ignore_msb);
+    switch (precision) {
+      case 4: amm = 0.673; break;
+      case 5: amm = 0.697; break;
+      case 6: amm = 0.709; break;
+      default: amm = 0.7213 / (1.0 + (1.079 / static_cast<double>(nreg))); break;
+    }
+    amm *= static_cast<double>(0x1ULL << (precision << 1U));
+  }
+  // internal_update :175-188
+  void update_via_hashval(uint64_t hval) {
+    uint64_t no_ignore = hval << ignored_msb;
+    uint64_t i = no_ignore >> (64 - precision);
+    uint64_t x = (no_ignore << precision) | lzc_mask;
+    uint8_t rank = x == 0 ? 65 : uint8_t(__builtin_clzll(x) + 1);   // leftmost_set_bit :70-76
+    if (rank > registers[i]) registers[i] = rank;
+  }
+  void update(uint64_t key) { update_via_hashval(hash_u64(hash_id, key, seed)); }   // :337-341
+  void merge(HyperLogLog64 const& o) { for (uint32_t i = 0; i < nreg; ++i) registers[i] = std::max(registers[i], o.registers[i]); }   // :190-197
+  void clear() { registers.assign(nreg, 0); }
+  // internal_estimate :201-236 (64-bit: no large-range correction)
+  double estimate() const {
+    double sum = 0.0;
+    for (uint32_t i = 0; i < nreg; ++i) sum += 1.0 / static_cast<double>(1ULL << registers[i]);
+    double est = amm / sum;
+    if (est <= static_cast<double>(5ULL * (nreg >> 1ULL))) {
+      uint32_t zeros = 0;
+      for (uint32_t i = 0; i < nreg; ++i) if (registers[i] == 0) ++zeros;
+      if (zeros > 0) return static_cast<double>(nreg) * std::log(static_cast<double>(nreg) / static_cast<double>(zeros));
+      return est;
+    }
+    return est;
   }
 };
 

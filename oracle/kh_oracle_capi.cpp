@@ -167,4 +167,14 @@ double ora_timed_find(void* h, const uint64_t* keys, uint64_t n, uint64_t* out_k
   return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// ---- HyperLogLog restatement
+void* ora_hll_create(uint32_t precision, uint32_t ignore_msb, int hash_id, uint64_t seed) { return new HyperLogLog64(precision, ignore_msb, hash_id, seed); }
+void ora_hll_destroy(void* h) { delete static_cast<HyperLogLog64*>(h); }
+void ora_hll_update(void* h, const uint64_t* keys, uint64_t n) { HyperLogLog64* p = static_cast<HyperLogLog64*>(h); for (uint64_t i = 0; i < n; ++i) p->update(keys[i]); }
+void ora_hll_update_via_hashval(void* h, const uint64_t* hv, uint64_t n) { HyperLogLog64* p = static_cast<HyperLogLog64*>(h); for (uint64_t i = 0; i < n; ++i) p->update_via_hashval(hv[i]); }
+void ora_hll_merge(void* h, void* o) { static_cast<HyperLogLog64*>(h)->merge(*static_cast<HyperLogLog64*>(o)); }
+void ora_hll_clear(void* h) { static_cast<HyperLogLog64*>(h)->clear(); }
+double ora_hll_estimate(void* h) { return static_cast<HyperLogLog64*>(h)->estimate(); }
+void ora_hll_registers(void* h, uint8_t* out) { HyperLogLog64* p = static_cast<HyperLogLog64*>(h); std::copy(p->registers.begin(), p->registers.end(), out); }
+
 }  // extern "C"

@@ -364,3 +364,123 @@ def smhasher_x64_128(data: bytes, seed: int):
     buf = C.create_string_buffer(data, len(data))
     smhasher().smh_x64_128(buf, len(data), seed, out.ctypes.data)
     return out
+
+
+# ---- HyperLogLog: oracle restatement and the real reference (oracle/_ref/libref_hll.so) ----------------------
+class _HLLBase:
+    _pfx = None
+    _L = None
+    h = None
+
+    def _f(self, n):
+        return getattr(self._L, self._pfx + n)
+
+    def update(self, keys):
+        keys = _k(keys)
+        self._f("update")(self.h, _p(keys, _u64p), len(keys))
+
+    def update_via_hashval(self, hv):
+        hv = _k(hv)
+        self._f("update_via_hashval")(self.h, _p(hv, _u64p), len(hv))
+
+    def merge(self, other):
+        self._f("merge")(self.h, other.h)
+
+    def clear(self):
+        self._f("clear")(self.h)
+
+    def estimate(self):
+        return float(self._f("estimate")(self.h))
+
+    def registers(self):
+        out = np.zeros(1 << self.precision, dtype=np.uint8)
+        self._f("registers")(self.h, _p(out, _u8p))
+        return out
+
+    def close(self):
+        if self.h:
+            self._f("destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _decl_hll(L, pfx, create_args):
+    getattr(L, pfx + "create").restype = C.c_void_p
+    getattr(L, pfx + "create").argtypes = create_args
+    getattr(L, pfx + "destroy").argtypes = [C.c_void_p]
+    getattr(L, pfx + "update").argtypes = [C.c_void_p, _u64p, C.c_uint64]
+    getattr(L, pfx + "update_via_hashval").argtypes = [C.c_void_p, _u64p, C.c_uint64]
+    getattr(L, pfx + "merge").argtypes = [C.c_void_p, C.c_void_p]
+    getattr(L, pfx + "clear").argtypes = [C.c_void_p]
+    getattr(L, pfx + "estimate").restype = C.c_double
+    getattr(L, pfx + "estimate").argtypes = [C.c_void_p]
+    getattr(L, pfx + "registers").argtypes = [C.c_void_p, _u8p]
+
+
+class OracleHLL(_HLLBase):
+    _pfx = "ora_hll_"
+
+    def __init__(self, precision=12, ignore_msb=0, hash_id=HASH_MURMUR3_X86, seed=43):
+        self._L = lib()
+        _decl_hll(self._L, self._pfx, [C.c_uint32, C.c_uint32, C.c_int, C.c_uint64])
+        self.precision = precision
+        self.h = self._L.ora_hll_create(precision, ignore_msb, hash_id, seed)
+
+
+_ref_hll = None
+
+
+def ref_hll_lib():
+    global _ref_hll
+    if _ref_hll is None:
+        path = os.path.join(HERE, "_ref", "libref_hll.so")
+        if not os.path.exists(path):
+            if not os.path.isdir("/root/reference/include/kmerhash"):
+                raise RuntimeError("reference HLL library not built and /root/reference absent")
+            build(("ref",))
+        L = C.CDLL(path)
+        _decl_hll(L, "ref_hll_", [C.c_uint32, C.c_int, C.c_uint64])
+        L.ref_serialize_pairs.argtypes = [_u64p, _u32p, C.c_uint64, C.c_char_p]
+        L.ref_deserialize_pairs.restype = C.c_int64
+        L.ref_deserialize_pairs.argtypes = [C.c_char_p, _u64p, _u32p, C.c_uint64]
+        L.ref_serialize_u64.argtypes = [_u64p, C.c_uint64, C.c_char_p]
+        _ref_hll = L
+    return _ref_hll
+
+
+def ref_hll_available():
+    return os.path.exists(os.path.join(HERE, "_ref", "libref_hll.so")) or os.path.isdir("/root/reference/include/kmerhash")
+
+
+class RefHLL(_HLLBase):
+    """the real fsc hyperloglog64<uint64_t, Hash, 12> from the reference tree"""
+    _pfx = "ref_hll_"
+    precision = 12
+
+    def __init__(self, ignore_msb=0, hash_id=HASH_MURMUR3_X86, seed=43):
+        self._L = ref_hll_lib()
+        self.h = self._L.ref_hll_create(ignore_msb, hash_id, seed)
+
+
+def ref_serialize_pairs(keys, vals, path):
+    keys, vals = _k(keys), _v(vals)
+    ref_hll_lib().ref_serialize_pairs(_p(keys, _u64p), _p(vals, _u32p), len(keys), path.encode())
+
+
+def ref_deserialize_pairs(path, cap):
+    k = np.zeros(cap, dtype=np.uint64)
+    v = np.zeros(cap, dtype=np.uint32)
+    n = ref_hll_lib().ref_deserialize_pairs(path.encode(), _p(k, _u64p), _p(v, _u32p), cap)
+    if n < 0:
+        raise RuntimeError("logic_error")
+    return k[:n], v[:n]
+
+
+def ref_serialize_u64(keys, path):
+    keys = _k(keys)
+    ref_hll_lib().ref_serialize_u64(_p(keys, _u64p), len(keys), path.encode())

@@ -92,6 +92,30 @@ def scenario(name, n, seed, hash_id, cap0=128, mn=0.35, mx=0.8):
     np.savez_compressed(os.path.join(HERE, "rh_oracle_%s.npz" % name), **rh)
 
 
+def hll_and_io():
+    """hll_ref.npz: registers/estimates of the REAL reference hyperloglog64<uint64_t,Hash,12>; io_ref_pairs.bin /
+    io_ref_keys.bin: files written by the REAL reference serialize_vector (io_utils.hpp:57-81)."""
+    out = {}
+    keys, vals = W.w1_benchmark_hashtables(200_000, seed=71)
+    for name, ign, hid, n in (("a", 0, O.HASH_MURMUR3_X86, 200_000), ("b", 3, O.HASH_MURMUR3_X86, 50_000),
+                              ("c", 0, O.HASH_FARM, 1000), ("d", 0, O.HASH_MURMUR3_X64, 37)):
+        r = O.RefHLL(ign, hid, 43)
+        r.update(keys[:n])
+        out["regs_" + name] = r.registers()
+        out["est_" + name] = np.float64(r.estimate())
+        out["cfg_" + name] = np.array([ign, hid, n], dtype=np.int64)
+    r1 = O.RefHLL(0, O.HASH_MURMUR3_X86, 43); r1.update(keys[:1000])
+    r2 = O.RefHLL(0, O.HASH_MURMUR3_X86, 43); r2.update(keys[1000:5000])
+    r1.merge(r2)
+    out["regs_merge"] = r1.registers(); out["est_merge"] = np.float64(r1.estimate())
+    hv = O.hash_batch(O.HASH_MURMUR3_X86, 43, keys[:5000])
+    r3 = O.RefHLL(0, O.HASH_MURMUR3_X86, 43); r3.update_via_hashval(hv)
+    out["regs_hv"] = r3.registers()
+    np.savez_compressed(os.path.join(HERE, "hll_ref.npz"), **out)
+    O.ref_serialize_pairs(keys[:500], vals[:500], os.path.join(HERE, "io_ref_pairs.bin"))
+    O.ref_serialize_u64(keys[:500], os.path.join(HERE, "io_ref_keys.bin"))
+
+
 if __name__ == "__main__":
     O.build(("all", "ref", "smhasher"))
     murmur_kat()
@@ -101,4 +125,5 @@ if __name__ == "__main__":
     scenario("farm_5k", 5000, 13, O.HASH_FARM)
     scenario("identity_5k", 5000, 17, O.HASH_IDENTITY)
     scenario("lpdefaults_3k", 3000, 19, O.HASH_MURMUR3_X86, 128, 0.2, 0.6)
+    hll_and_io()
     print("golden fixtures written to", HERE)
