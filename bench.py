@@ -36,8 +36,11 @@ B_INSERT_NEW, B_INSERT_DUP, B_FIND_HIT, B_FIND_MISS = 50, 33, 41, 9
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def gen_inputs(rank, n, nq):
+def gen_inputs(rank, n, nq, workload="w2"):
     from kmerhash_amd import workloads as W
+    if workload == "w1":                             # benchmark_hashtables shape: mean multiplicity 5.5 (not the metric's config)
+        keys, vals = W.w1_benchmark_hashtables(n, seed=23 + rank)
+        return keys, vals, keys[:nq].copy()
     keys = W.distinct_u64(n, seed=1 + rank)          # W2: distinct uniform u64 (bijective splitmix64 of a counter)
     vals = np.arange(n, dtype=np.uint32)
     q = keys[:nq].copy()                             # all hits (BenchmarkHashTables.cpp:1062-1066: first N/Q inputs)
@@ -67,6 +70,8 @@ def main():
     ap.add_argument("--keys", type=int, default=KEYS_PER_GPU)
     ap.add_argument("--queries", type=int, default=QUERIES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="w2", choices=["w2", "w1"],
+                    help="w2 = configs[1] (default, the metric's workload); w1 = benchmark_hashtables shape (x5.5 multiplicity), informational")
     ap.add_argument("--chunks", type=int, default=1, help="N>1: pieces of the exchange/insert overlap (1 = exchange, then one bulk insert)")
     args = ap.parse_args()
 
@@ -90,7 +95,8 @@ def main():
         local_rank = 0
     dev = torch.device("cuda", local_rank)
 
-    keys, vals, q = gen_inputs(rank, args.keys, args.queries)
+    keys, vals, q = gen_inputs(rank, args.keys, args.queries, args.workload)
+    n_distinct = len(np.unique(keys)) if args.workload == "w1" else args.keys
     dk = torch.from_numpy(keys.view(np.int64)).to(dev)
     dv = torch.from_numpy(vals.view(np.int32)).to(dev)
     dq = torch.from_numpy(q.view(np.int64)).to(dev)
@@ -161,9 +167,12 @@ def main():
 
     # size-independent parity properties at full size (the oracle cannot run 1e8 keys in seconds):
     # every distinct key inserted exactly once, every query found
-    assert g_ins == args.keys * world, (g_ins, args.keys * world)
+    if args.workload == "w2":
+        assert g_ins == args.keys * world, (g_ins, args.keys * world)
+        assert g_size == args.keys * world
+    elif not distributed:
+        assert g_ins == n_distinct and g_size == n_distinct, (g_ins, n_distinct)
     assert g_hit == args.queries * world, (g_hit, args.queries * world)
-    assert g_size == args.keys * world
 
     if rank == 0:
         ops_per_step = (args.keys + args.queries) * world
@@ -198,7 +207,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[1]: Robin Hood table, %d distinct random 64-bit k-mers per GPU (max load 0.8 -> "
+            "config": {"workload": ("(informational, benchmark_hashtables shape x5.5 multiplicity) " if args.workload == "w1" else "") + "configs[1]: Robin Hood table, %d distinct random 64-bit k-mers per GPU (max load 0.8 -> "
                                    "capacity %d, load %.3f), murmur3avx64 seed 43, then %d all-hit finds per GPU%s"
                                    % (args.keys, state[3], state[2] / state[3], args.queries,
                                       "; keys sharded by murmur3(seed 9876543) over RCCL all_to_all" if distributed else ""),

@@ -131,6 +131,14 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t nranks,
                            uint64_t* out_keys_dev, uint32_t* out_vals_dev /* may be NULL */,
                            uint64_t* counts_host, int device, void* hip_stream);
 
+/* ---- k-mer generation front end (BenchmarkKmerCounter.cpp:1655-1706 reads sequences through kmerind's
+ *      KmerParser, which is not part of the reference tree: PARITY UNPINNED, the definition below is this library's):
+ *      every window of k valid bases (ACGT, either case) of `seq` yields one 2-bit packed k-mer (first base most
+ *      significant, A=0 C=1 G=2 T=3), in sequence order; any other byte ends the run (pass read/sequence lines separated
+ *      by '\n').  canonical != 0: min(k-mer, reverse complement).  out_kmers needs room for n entries. */
+kh_status kh_kmers_from_sequence(const void* seq /*[h|d] u8[n]*/, uint64_t n, uint32_t k /*1..32*/, int canonical, kh_mem where,
+                                 uint64_t* out_kmers /*[h|d]*/, uint64_t* n_out, int device, void* hip_stream);
+
 /* ---- HyperLogLog cardinality estimator: fsc::hyperloglog64<T, Hash, precision> (hyperloglog64.hpp:142-475),
  *      64-bit hash values: register = top `precision` bits after dropping `ignore_msb` bits, rank = leading zeros + 1
  *      (:175-188); estimate() = harmonic mean with the linear-counting branch below 5m/2 (:201-236).  Registers are

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_compact_hits(const uint8_t* __restrict_
   uint32_t x = wpre + incl - c;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if ((fw >> (8 * j)) & 0xFFu) { lk[x] = q[base + j]; lv[x] = vals[base + j]; ++x; }
+    if ((fw >> (8 * j)) & 0xFFu) { lk[x] = q[base + j]; lv[x] = vals ? vals[base + j] : 0u; ++x; }
   }
   __syncthreads();
   const uint64_t obase = tile_off[blockIdx.x];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_compact_hits(const uint8_t* __restrict_
       *reinterpret_cast<uint4*>(out_pairs16 + (obase + s) * 16) = w;
     } else {
       out_keys[obase + s] = lk[s];
-      out_vals[obase + s] = lv[s];
+      if (out_vals) out_vals[obase + s] = lv[s];
     }
   }
 }
@@ -1115,5 +1115,42 @@ __global__ void k_hll_update(const uint64_t* __restrict__ in, uint64_t n, uint64
 __global__ void k_hll_merge(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t m) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) { const uint32_t a = dst[i], b = src[i]; dst[i] = a > b ? a : b; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-mer generation front end (the reference gets this from kmerind's KmerParser, which is absent):
+// every window of k valid bases (A,C,G,T, either case) of a byte sequence becomes one 2-bit packed k-mer, first
+// base in the most significant position (bliss::common::Kmer::nextFromChar order), A=0 C=1 G=2 T=3; any other byte
+// (newline, N, ...) breaks the run.  CANON: min(k-mer, reverse complement).  One lane rolls over 64 start positions.
+// ---------------------------------------------------------------------------------------------
+#define KH_KMER_STRIP 64
+__device__ __forceinline__ uint32_t kh_dna_code(uint32_t c) {
+  c &= 0xDFu;
+  return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+}
+template <bool CANON>
+__global__ void k_kmers(const uint8_t* __restrict__ seq, uint64_t n, uint32_t k, uint64_t* __restrict__ kmers, uint8_t* __restrict__ flags) {
+  const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * KH_KMER_STRIP;
+  if (p0 >= n) return;
+  const uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+  uint64_t fw = 0, rc = 0;
+  uint32_t run = 0;
+  for (uint32_t j = 0; j < KH_KMER_STRIP + k - 1; ++j) {
+    const uint64_t pos = p0 + j;
+    if (pos >= n) break;
+    const uint32_t code = kh_dna_code(seq[pos]);
+    if (code > 3u) run = 0;
+    else {
+      fw = ((fw << 2) | code) & mask;
+      rc = (rc >> 2) | ((uint64_t)(3u - code) << (2 * (k - 1)));
+      ++run;
+    }
+    if (j >= k - 1) {
+      const uint64_t start = pos - (k - 1);
+      const bool ok = run >= k;
+      flags[start] = ok ? 1 : 0;
+      if (ok) kmers[start] = CANON ? (fw < rc ? fw : rc) : fw;
+    }
+  }
 }
 

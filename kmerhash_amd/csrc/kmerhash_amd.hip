@@ -937,6 +937,57 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64
   return KH_OK;
 }
 
+// ---- k-mer generation front end ----------------------------------------------------------------------
+kh_status kh_kmers_from_sequence(const void* seq, uint64_t n, uint32_t k, int canonical, kh_mem where,
+                                 uint64_t* out_kmers, uint64_t* n_out, int device, void* stream_) {
+  kh_table* t = nullptr;
+  if (n_out) *n_out = 0;
+  if (k < 1 || k > 32 || !n_out) return KH_ERR_INVALID;
+  if (n < k) return KH_OK;
+  if (!seq || !out_kmers) return KH_ERR_INVALID;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(device));
+  const uint64_t ntl = (n + KH_CMP_TILE - 1) / KH_CMP_TILE;
+  // one pooled block: [seq copy (host input)] [all k-mers 8n] [flags n] [tile sums] [tile offsets] [compacted out (host output)]
+  const size_t sz_seq = where == KH_MEM_HOST ? ((n + 255) & ~size_t(255)) : 0;
+  const size_t sz_km = n * 8, sz_fl = (n + 255) & ~size_t(255), sz_sum = ((ntl * 4 + 255) & ~size_t(255)), sz_off = (ntl + 1) * 8;
+  const size_t sz_out = where == KH_MEM_HOST ? n * 8 : 0;
+  char* blk = nullptr;
+  HIPCHK(pool_alloc(device, sz_seq + sz_km + sz_fl + sz_sum + sz_off + 256 + sz_out, reinterpret_cast<void**>(&blk)));
+  const uint8_t* dseq = static_cast<const uint8_t*>(seq);
+  char* p = blk;
+  if (where == KH_MEM_HOST) { dseq = reinterpret_cast<uint8_t*>(p); p += sz_seq; }
+  uint64_t* km = reinterpret_cast<uint64_t*>(p); p += sz_km;
+  uint8_t* fl = reinterpret_cast<uint8_t*>(p); p += sz_fl;
+  uint32_t* sums = reinterpret_cast<uint32_t*>(p); p += sz_sum;
+  uint64_t* offs = reinterpret_cast<uint64_t*>(p); p += (sz_off + 255) & ~size_t(255);
+  uint64_t* dout = where == KH_MEM_HOST ? reinterpret_cast<uint64_t*>(p) : out_kmers;
+  hipError_t e = hipSuccess;
+  if (where == KH_MEM_HOST) e = hipMemcpyAsync(const_cast<uint8_t*>(dseq), seq, n, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(fl, 0, sz_fl, stream);
+  if (e == hipSuccess) {
+    const uint64_t strips = (n + KH_KMER_STRIP - 1) / KH_KMER_STRIP;
+    const uint32_t grid = (uint32_t)((strips + 255) / 256);
+    if (canonical) hipLaunchKernelGGL((k_kmers<true>), dim3(grid), dim3(256), 0, stream, dseq, n, k, km, fl);
+    else hipLaunchKernelGGL((k_kmers<false>), dim3(grid), dim3(256), 0, stream, dseq, n, k, km, fl);
+    hipLaunchKernelGGL(k_flag_tile_sums, dim3((uint32_t)ntl), dim3(256), 0, stream, fl, n, sums);
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, stream, sums, ntl, offs);
+    hipLaunchKernelGGL(k_compact_hits, dim3((uint32_t)ntl), dim3(256), 0, stream, fl, km, (const uint32_t*)nullptr, n, offs, dout, (uint32_t*)nullptr, (uint8_t*)nullptr);
+    e = hipGetLastError();
+  }
+  uint64_t total = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, offs + ntl, 8, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess && where == KH_MEM_HOST && total) {
+    e = hipMemcpyAsync(out_kmers, dout, total * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  pool_free(device, blk);
+  if (e != hipSuccess) return KH_ERR_HIP;
+  *n_out = total;
+  return KH_OK;
+}
+
 // ---- HyperLogLog (hyperloglog64.hpp) --------------------------------------------------------------
 }  // extern "C"
 struct kh_hll {

@@ -1,0 +1,108 @@
+"""k-mer counting front end: the BenchmarkKmerCounter shape (BenchmarkKmerCounter.cpp:1476-1787: read
+FASTQ/FASTA -> k-mers -> counting insert -> write (k-mer, count) tuples) on the GPU tables.
+
+The reference takes its parser and k-mer type from kmerind (absent), so the k-mer definition here is this library's
+(see kh_kmers_from_sequence in include/kmerhash_amd.h): 2-bit packed, first base most significant, A=0 C=1 G=2 T=3,
+windows containing any other byte are skipped, canonical = min(k-mer, reverse complement)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+from .table import _Buf, hashmap_robinhood_doubling, torch
+
+
+def sequences_from_fastq(buf):
+    """FASTQ text (bytes / uint8 array) -> uint8 array holding only the sequence lines, each followed by '\\n'
+    (records are 4 lines: @id, sequence, +, quality)."""
+    raw = bytes(buf) if isinstance(buf, (bytes, bytearray)) else np.asarray(buf, dtype=np.uint8).tobytes()
+    seqs = raw.split(b"\n")[1::4]
+    if not seqs:
+        return np.zeros(0, dtype=np.uint8)
+    return np.frombuffer(b"\n".join(seqs) + b"\n", dtype=np.uint8).copy()
+
+
+def sequences_from_fasta(buf):
+    """FASTA text -> sequence bytes; header lines are replaced by a single '\\n' so that k-mers never span records
+    (line breaks inside a record are removed)."""
+    a = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else np.asarray(buf, dtype=np.uint8)
+    lines = bytes(a).split(b"\n")
+    parts = []
+    for ln in lines:
+        if ln.startswith(b">"):
+            parts.append(b"\n")
+        else:
+            parts.append(ln.strip())
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+
+
+def kmers_from_sequence(seq, k=31, canonical=True, device=0):
+    """-> packed k-mers (numpy uint64 for host input, torch int64 CUDA tensor for device input), sequence order"""
+    L = K.lib()
+    b = _Buf(seq, np.uint8, 1)
+    n_out = C.c_uint64()
+    if b.where == K.KH_MEM_DEVICE:
+        out = torch.empty(max(b.n, 1), dtype=torch.int64, device=b.device)
+        optr = out.data_ptr()
+        stream = torch.cuda.current_stream(device).cuda_stream
+    else:
+        out = np.zeros(max(b.n, 1), dtype=np.uint64)
+        optr = out.ctypes.data
+        stream = None
+    st = L.kh_kmers_from_sequence(b.ptr, b.n, k, 1 if canonical else 0, b.where, optr, C.byref(n_out), device, stream)
+    if st != K.KH_OK:
+        raise K.KhError(st, "kh_kmers_from_sequence")
+    return out[: n_out.value]
+
+
+class KmerCounter:
+    """counting index: k-mer -> number of occurrences (Reducer = std::plus, value 1 per occurrence)"""
+
+    def __init__(self, k=31, canonical=True, hash="farm", min_load_factor=0.35, max_load_factor=0.8, device=0):
+        self.k, self.canonical, self.device = k, canonical, device
+        self.table = hashmap_robinhood_doubling(128, min_load_factor, max_load_factor, hash=hash, seed=43, device=device)
+
+    def add_sequences(self, seq):
+        km = kmers_from_sequence(seq, self.k, self.canonical, self.device)
+        if len(km):
+            self.table.insert_reduce_plus(km)
+        return len(km)
+
+    def add_fastq(self, buf):
+        return self.add_sequences(sequences_from_fastq(buf))
+
+    def counts(self):
+        return self.table.to_vector()
+
+    def write(self, filename, count_dtype=np.uint16):
+        """raw (k-mer, count) tuples, sizeof(KmerType) + sizeof(CountType) bytes each, no padding
+        (BenchmarkKmerCounter.cpp:1022-1059 copyToByteArray; CountType = uint16_t there, wrapping like std::plus)"""
+        k, v = self.counts()
+        rec = np.zeros(len(k), dtype=np.dtype([("kmer", "<u8"), ("count", np.dtype(count_dtype).newbyteorder("<"))]))
+        rec["kmer"] = k
+        rec["count"] = v.astype(count_dtype)
+        rec.tofile(filename)
+        return len(k)
+
+    def close(self):
+        self.table.close()
+
+
+def synthetic_fastq(n_reads, read_len=150, genome_len=1_000_000, seed=7, n_rate=0.001):
+    """random genome, uniformly sampled reads on both strands, a sprinkle of N's (SURVEY §8d W5 shape, scaled)"""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, genome_len, dtype=np.uint8)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    starts = rng.integers(0, genome_len - read_len, n_reads)
+    rev = rng.integers(0, 2, n_reads).astype(bool)
+    out = []
+    for i in range(n_reads):
+        r = genome[starts[i]: starts[i] + read_len]
+        if rev[i]:
+            r = comp[r[::-1]]
+        s = lut[r].copy()
+        m = rng.random(read_len) < n_rate
+        s[m] = ord("N")
+        out.append(b"@r%d\n" % i + s.tobytes() + b"\n+\n" + b"I" * read_len + b"\n")
+    return b"".join(out)
