@@ -138,19 +138,6 @@ __global__ void k_erase_mark(KhSlots T, const uint64_t* __restrict__ q, uint64_t
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_erased, (unsigned long long)mine);
 }
 
-// overwrite the value of keys that are present (kh_update's second half)
-template <int KIND, int HASH>
-__global__ void k_assign_existing(KhSlots T, const uint64_t* __restrict__ q, const uint32_t* __restrict__ v, uint64_t n, uint64_t seed) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t mask = T.cap - 1;
-  for (; i < n; i += stride) {
-    uint64_t key = q[i];
-    uint64_t pos = kh_find_pos<KIND>(T.keys, T.info, mask, kh_hash64<HASH>(key, seed) & mask, key);
-    if (pos != KH_NONE) T.vals[pos] = v[i];
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // stream compaction of find hits (find(Iter,Iter) returns only the hits, in query order)
 // ---------------------------------------------------------------------------------------------

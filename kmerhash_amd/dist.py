@@ -77,11 +77,15 @@ class ShardedTable:
     def local(self):
         return self.b.table
 
+    def _host_staged(self):
+        return self.p > 1 and dist.get_backend(self.group) == "gloo" and self.b.torch_device.type == "cuda"
+
     # ---- exchange helpers ---------------------------------------------------------------------------
     def _exchange_counts(self, send_counts):
         if self.p == 1 and not FORCE_COLLECTIVES:
             return list(send_counts)
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=self.b.torch_device)
+        dev = torch.device("cpu") if self._host_staged() else self.b.torch_device
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.group)       # mxx::all2all(send_counts) :1024
         return [int(x) for x in rc.cpu()]
@@ -89,6 +93,11 @@ class ShardedTable:
     def _a2av(self, send, send_counts, recv_counts):
         if self.p == 1 and not FORCE_COLLECTIVES:
             return send
+        if self._host_staged():
+            # rehearsal on a backend without device collectives (gloo): stage through host memory
+            hout = torch.empty(sum(recv_counts), dtype=send.dtype)
+            dist.all_to_all_single(hout, send.cpu(), output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group)
+            return hout.to(send.device)
         out = self.b.empty(sum(recv_counts), send.dtype)
         dist.all_to_all_single(out, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
                                group=self.group)               # khmxx::distribute_permuted (mxx::all2allv) :1126
@@ -162,7 +171,7 @@ class ShardedTable:
         n = self.local.size()
         if self.p == 1 and not FORCE_COLLECTIVES:
             return n
-        t = torch.tensor([n], dtype=torch.int64, device=self.b.torch_device)
+        t = torch.tensor([n], dtype=torch.int64, device=torch.device("cpu") if self._host_staged() else self.b.torch_device)
         dist.all_reduce(t, group=self.group)
         return int(t.item())
 

@@ -299,3 +299,41 @@ def test_reducer_plus_kmer_counting(kname, cls, kind):
         assert np.array_equal(g.export_info(), from_scratch.export_info())   # layout is the canonical one
         from_scratch.close()
     g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_operation_sequences(oracle, kname, cls, kind, seed):
+    """differential fuzz: random mixes of insert / update / reducer / count / find / erase / erase_one / reserve / rehash
+    batches of random sizes on one table, state compared with the oracle after every step"""
+    rng = np.random.default_rng(1000 * seed + kind)
+    g = cls(128, 0.35, 0.8)
+    o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    universe = W.splitmix64(np.arange(60_000, dtype=np.uint64) + np.uint64(seed << 24))
+    for step in range(60):
+        op = int(rng.integers(0, 9))
+        m = int(rng.choice([0, 1, 3, 50, 2000, 20_000]))
+        ks = universe[rng.integers(0, len(universe), m)]
+        vs = rng.integers(0, 2**32, m, dtype=np.uint32)
+        if op <= 2:
+            assert g.insert(dev(ks), dev(vs)) == o.insert(ks, vs), step
+        elif op == 3:
+            g.update(ks, vs)
+            for k, v in zip(ks.tolist(), vs.tolist()):
+                o.update_one(k, v)
+        elif op == 4:
+            check_queries(g, o, ks) if m else None
+        elif op == 5:
+            assert g.erase(dev(ks)) == o.erase(ks), step
+        elif op == 6:
+            for k in ks[:5]:
+                assert g.erase_one(int(k)) == o.erase_one(int(k))
+        elif op == 7:
+            r = int(rng.integers(0, 50_000))
+            g.reserve(r); o.reserve(r)
+        else:
+            b = int(rng.choice([1024, 4096, 1 << 16, 1 << 18]))
+            if o.size() <= b * 0.5:
+                g.rehash(b); o.rehash(b)
+        check_state(g, o, kind)
+    g.close()
