@@ -913,6 +913,263 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParam
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused bulk build (empty table, one partition == one chunk of the predicted capacity): de-dup, home count, carry
+// and placement in ONE kernel -- the distinct elements never leave LDS.  The only inter-workgroup dependency is the
+// run-over of the previous chunk.  A chunk with n_c + KH_XB <= L elements publishes its run-over before it knows its
+// own carry-in (a carry-in of at most KH_XB slots cannot reach its end), so the look-back is one chunk deep.  Chunk c
+// is handled by workgroup blockIdx c: the dispatcher is observed to start workgroups in index order, so the predecessor
+// is running or done and the poll lasts microseconds -- but nothing relies on it: the poll is BOUNDED, a timeout raises a
+// flag and the host repeats the batch on the general path (a ticket counter would make the order a guarantee, but
+// 65536 returning atomics on one word cost 2.3 ms here: measured 3.7 ms with ticket vs 1.4 ms without).  Chunk 0
+// depends on the LAST chunk (circular table); it only publishes, parks its distinct keys in global memory and is
+// placed by k_chunk_place after the kernel.  The published word is one naturally aligned 8-byte granule {valid, run-over, count} that carries its own data: it is
+// written and polled with RELAXED agent-scope atomics (L1-bypassing `sc1` accesses; MI355X guide G16 'R2 granule').
+// A release store here would write back the XCD's whole dirty L2 (65536 times, with 1.7 GB of table stores in
+// flight): measured 14 ms instead of 1.6.  Anything outside these assumptions
+// (a partition larger than the LDS staging area, a carry-in above KH_XB, a poll that times out) raises a flag and the
+// host repeats the batch on the general path (k_dedup / k_chunk_count / k_chunk_carry / k_chunk_place).
+// ---------------------------------------------------------------------------------------------
+#define KH_XB 127u               // bound on a carry-in that may be ignored when publishing early
+#define KH_FSPILL 128u           // run-over slots staged in LDS by the fused kernel
+struct KhFusedParams {
+  const ulonglong2* rec; const uint64_t* part_off; uint32_t PB;
+  KhSlots New; uint64_t seed; int mode;                  // KH_DEDUP_FIRST or KH_DEDUP_PLUS
+  unsigned long long* pub;                               // [nch] zero-initialised: bit63 valid | run-over << 32 | count
+  uint64_t* ck0; uint32_t* cv0; uint16_t* homecnt0;      // chunk 0 parked here: distinct keys/values (KH_DD_M), home counts (KH_L)
+  uint32_t* maxidx;                                      // [nch] per chunk: max(first-occurrence index + 1) (k_fused_totals reduces)
+  // early give-up on duplicate-heavy batches: after 64 chunks the distinct/record ratio predicts the final size; if even
+  // 1.15x of it fits the next smaller capacity the speculation is hopeless, the remaining workgroups return at once
+  uint64_t n_total, half_max_load;
+  uint32_t* est;                                         // [0] distinct so far, [1] records so far, [2] abort
+  uint32_t* flags;
+};
+template <int KIND, int HASH>
+__global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams P) {
+  __shared__ unsigned long long lk[KH_DD_M];
+  __shared__ unsigned long long liv[KH_DD_M];
+  __shared__ uint32_t set[KH_HS];               // de-dup index set, later cnt/fill = set[0..L) and start = set[L..2L)
+  // the chunk image is kept as 16-bit indices into the staged records (0xFFFF = empty slot): 4.3 KB instead of the
+  // 28 KB of a (key, value, info) image, which keeps the kernel at 53.7 KB of LDS = 3 workgroups per CU
+  __shared__ uint16_t simg[KH_L + KH_FSPILL];
+  __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
+  __shared__ uint32_t s_chunk, s_x, s_max, s_abort;
+  __shared__ long long s_pend;
+  static_assert(KH_HS >= 2 * KH_L, "set[] is reused as cnt/fill + start");
+  uint32_t* cnt = set;
+  uint32_t* start = set + KH_L;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t cap = P.New.cap, mask_n = cap - 1;
+  const uint32_t nch = (uint32_t)(cap >> KH_LB);          // host guarantees cap >= 2 * KH_L
+  if (tid == 0) {
+    s_chunk = blockIdx.x;
+    s_max = 0;
+    s_abort = __hip_atomic_load(&P.est[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const uint32_t c = s_chunk;
+  const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
+  const uint64_t beg = P.part_off[q];
+  const uint32_t m = (uint32_t)(P.part_off[q + 1] - beg);
+  const uint64_t Sc = (uint64_t)c * KH_L;
+  const unsigned long long VALID = 1ull << 63;
+  const bool aborted = s_abort != 0;
+  if (m > KH_DD_M || aborted) {      // does not fit the staging area / speculation given up: general path
+    if (tid == 0) {
+      // (an aborted launch was flagged once by the workgroup that gave up: 65 K atomics on one word would cost 2 ms)
+      if (!aborted) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+      __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // ---- de-dup (as k_dedup, single round)
+  for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+  for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = P.rec[beg + i]; lk[i] = rr.x; liv[i] = rr.y; }
+  for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
+  __syncthreads();
+  uint32_t rep_mask = 0;
+  for (uint32_t x0 = 0, it = 0; x0 < m; x0 += KH_CHUNK_THREADS, ++it) {
+    const uint32_t x = x0 + tid;
+    if (x < m) {
+      const unsigned long long key = lk[x];
+      uint32_t slot = (uint32_t)kh_fmix64(key + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
+      for (;;) {
+        uint32_t cur = set[slot];
+        if (cur == 0) {
+          cur = atomicCAS(&set[slot], 0u, x + 1u);
+          if (cur == 0) { rep_mask |= 1u << it; break; }
+        }
+        const uint32_t rep = cur - 1u;
+        if (lk[rep] == key) {
+          const unsigned long long iv = liv[x];
+          if (P.mode == KH_DEDUP_FIRST) atomicMin(&liv[rep], iv); else atomicAdd(&liv[rep], iv & 0xFFFFFFFFull);
+          break;
+        }
+        slot = (slot + 1) & (KH_HS - 1);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- home counts of the distinct keys (set[] is dead from here on)
+  for (uint32_t i = tid; i < 2 * KH_L; i += KH_CHUNK_THREADS) set[i] = 0;
+  __syncthreads();
+  uint32_t hb[KH_DD_M / KH_CHUNK_THREADS];
+  uint32_t my_max = 0;
+#pragma unroll
+  for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+    hb[it] = 0;
+    const uint32_t x = it * KH_CHUNK_THREADS + tid;
+    if ((rep_mask >> it) & 1u) {
+      hb[it] = (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc);
+      atomicAdd(&cnt[hb[it]], 1u);
+      if (P.mode == KH_DEDUP_FIRST) { const uint32_t ix = (uint32_t)(liv[x] >> 32) + 1u; my_max = ix > my_max ? ix : my_max; }
+    }
+  }
+  my_max = kh_wave_max(my_max);
+  if ((tid & 63) == 0 && my_max) atomicMax(&s_max, my_max);
+  __syncthreads();
+  uint32_t cb[KH_HOMES_PER_THREAD];
+  KhMP v; v.A = KH_MP_NEG; v.n = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+    const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+    cb[j] = cnt[b];
+    KhMP h; h.A = (long long)b + cb[j]; h.n = cb[j];
+    v = kh_mp_combine(v, h);
+  }
+  KhMP total;
+  const KhMP excl = kh_block_scan_mp(v, s_wtot, &total);
+  const uint32_t n_c = (uint32_t)total.n;
+  const long long spill0 = total.A > (long long)KH_L ? total.A - (long long)KH_L : 0;
+  const bool early = n_c + KH_XB <= KH_L;
+  if (c == 0) {     // circular table: chunk 0 follows the last chunk -> publish, park, and leave the placement to the tail launch
+    if (tid == 0) {
+      if (!early) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+      __hip_atomic_store(&P.pub[0], VALID | ((unsigned long long)spill0 << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      P.maxidx[0] = s_max;
+      s_x = 0;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) P.homecnt0[tid * KH_HOMES_PER_THREAD + j] = (uint16_t)cb[j];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      const bool rep = (rep_mask >> it) & 1u;
+      const uint32_t pos = kh_wave_append(rep, &s_x);
+      if (rep) { const uint32_t x = it * KH_CHUNK_THREADS + tid; P.ck0[pos] = lk[x]; P.cv0[pos] = (uint32_t)liv[x]; }
+    }
+    return;
+  }
+  // ---- publish / look back
+  if (tid == 0) {
+    if (c < 64) {     // the first 64 chunks vote on the duplicate ratio (same-address atomics are kept off the other 65 K)
+      const uint32_t sn = atomicAdd(&P.est[0], n_c) + n_c, sm = atomicAdd(&P.est[1], m) + m;
+      if ((c == 63 || (nch < 64 && c == nch - 1)) && sm > 0) {
+        const double dhat = (double)P.n_total * (double)sn / (double)sm * 1.15;
+        if (dhat <= (double)P.half_max_load) {
+          atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+          __hip_atomic_store(&P.est[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (early) __hip_atomic_store(&P.pub[c], VALID | ((unsigned long long)spill0 << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t pc = c - 1;
+    unsigned long long w = 0;
+    const long long t0 = clock64();
+    for (;;) {
+      w = __hip_atomic_load(&P.pub[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w & VALID) break;
+      if (clock64() - t0 > (1ll << 23)) { atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u); w = VALID; break; }   // bounded: ~4 ms, then general path
+      __builtin_amdgcn_s_sleep(4);
+    }
+    const uint32_t x = (uint32_t)((w >> 32) & 0x7FFFFFFFu);
+    if (x > KH_XB) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);       // a carry chain: general path
+    if (!early) {
+      const long long e = (long long)x + n_c;
+      const long long pe = total.A > e ? total.A : e;
+      const long long sp = pe > (long long)KH_L ? pe - (long long)KH_L : 0;
+      __hip_atomic_store(&P.pub[c], VALID | ((unsigned long long)sp << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_x = x;
+    P.maxidx[c] = s_max;
+  }
+  __syncthreads();
+  // ---- placement with the carry-in (as k_chunk_place)
+  const long long xr = (long long)s_x;
+  long long p = excl.A > xr + excl.n ? excl.A : xr + excl.n;
+#pragma unroll
+  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+    const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+    const long long st = p > (long long)b ? p : (long long)b;
+    start[b] = (uint32_t)st;
+    p = st + cb[j];
+    cnt[b] = 0;                 // becomes the fill counter
+  }
+  if (tid == KH_CHUNK_THREADS - 1) s_pend = p;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+    if ((rep_mask >> it) & 1u) {
+      const uint32_t x = it * KH_CHUNK_THREADS + tid;
+      const uint32_t b = hb[it];
+      const uint32_t r = atomicAdd(&cnt[b], 1u);
+      const uint32_t prel = start[b] + r;
+      uint32_t dist = prel - b;
+      if (KIND == KHK_RH && dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
+      if (prel < KH_L + KH_FSPILL) simg[prel] = (uint16_t)x;
+      else {
+        const uint64_t pos = (Sc + prel) & mask_n;
+        P.New.keys[pos] = lk[x]; P.New.vals[pos] = (uint32_t)liv[x];
+        P.New.info[pos] = KIND == KHK_RH ? (uint8_t)(0x80u | dist) : (uint8_t)0x00;
+      }
+    }
+  }
+  __syncthreads();
+  long long pend = s_pend;
+  if (pend < (long long)KH_L) pend = KH_L;
+  const uint32_t lo = (uint32_t)xr;
+  const uint32_t hi = pend < (long long)(KH_L + KH_FSPILL) ? (uint32_t)pend : (KH_L + KH_FSPILL);
+  for (uint32_t s0 = lo + tid; s0 < hi; s0 += KH_CHUNK_THREADS) {
+    const uint64_t pos = (Sc + s0) & mask_n;
+    const uint32_t x = simg[s0];
+    if (x == 0xFFFFu) {
+      P.New.keys[pos] = 0; P.New.vals[pos] = 0;
+      P.New.info[pos] = KIND == KHK_RH ? (uint8_t)0x00 : (uint8_t)0x40;
+    } else {
+      const uint64_t key = lk[x];
+      P.New.keys[pos] = key;
+      P.New.vals[pos] = (uint32_t)liv[x];
+      if (KIND == KHK_RH) {     // distance = slot - home; the home is re-derived from the key (cheaper than 2 KB of LDS)
+        uint32_t dist = s0 - (uint32_t)((kh_hash64<HASH>(key, P.seed) & mask_n) - Sc);
+        if (dist > 127u) dist = 127u;
+        P.New.info[pos] = (uint8_t)(0x80u | dist);
+      } else P.New.info[pos] = 0x00;
+    }
+  }
+}
+
+// carry-in of chunk 0 = run-over of the last chunk (circular table)
+__global__ void k_fused_tail_carry(const unsigned long long* __restrict__ pub, uint32_t nch, long long* __restrict__ xcarry0) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) xcarry0[0] = (long long)((pub[nch - 1] >> 32) & 0x7FFFFFFFull);
+}
+
+// totals of a fused build: sum of the per-chunk counts (low word of the published granules) and max of maxidx
+__global__ void k_fused_totals(const unsigned long long* __restrict__ pub, const uint32_t* __restrict__ maxidx, uint32_t nch,
+                               unsigned long long* __restrict__ totals) {
+  __shared__ unsigned long long ws[16];
+  __shared__ uint32_t wm[16];
+  unsigned long long sum = 0; uint32_t mx = 0;
+  for (uint32_t c = threadIdx.x; c < nch; c += 1024) { sum += pub[c] & 0xFFFFFFFFull; const uint32_t v = maxidx[c]; mx = v > mx ? v : mx; }
+  for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off, 64); const uint32_t o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
+  if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = sum; wm[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0; uint32_t m = 0;
+    for (int w = 0; w < 16; ++w) { t += ws[w]; m = wm[w] > m ? wm[w] : m; }
+    totals[0] = t; totals[1] = m;
+  }
+}
+
 // RH displacement histogram (REPROBE_STAT-style oracle)
 __global__ void k_disp_hist(const uint8_t* __restrict__ info, uint64_t cap, unsigned long long* __restrict__ out128) {
   __shared__ uint32_t h[128];

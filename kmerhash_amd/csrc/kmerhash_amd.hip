@@ -17,6 +17,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include <map>
 #include <mutex>
@@ -427,6 +428,7 @@ uint64_t capacity_after(const kh_table* t, uint64_t cap, uint64_t lsize, uint64_
 }
 
 enum { INS_FIRST = 0, INS_UPDATE = 1, INS_PLUS = 2 };
+bool g_disable_fused = getenv("KH_DISABLE_FUSED_BUILD") != nullptr;   // test hook: force the general path
 
 // core of insert/update for one batch of device-resident input (n < 2^32 - 16)
 kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
@@ -439,6 +441,76 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   Partitioned R;
   kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, PB, R);
   if (st != KH_OK) return st;
+  // ---- fused bulk build: empty table, moderate load factor, at least two chunks.  Speculates that the capacity the
+  // reference's rule yields equals cap_u (true when the batch holds few duplicates); otherwise falls through.
+  if (t->lsize == 0 && cap_u >= 2 * (uint64_t)KH_L && t->max_lf <= 0.9f && PB == log2u(cap_u >> KH_LB) && !g_disable_fused) {
+    const uint32_t nch = (uint32_t)(cap_u >> KH_LB);
+    KhSlots nw;
+    st = fresh_slots(t, cap_u, nw);
+    if (st != KH_OK) return st;
+    char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
+    const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
+    TAKE(blk, char, sz_all);
+    TAKE(maxidx, uint32_t, nch);
+    TAKE(ck0, uint64_t, KH_DD_M); TAKE(cv0, uint32_t, KH_DD_M); TAKE(hc0, uint16_t, KH_L); TAKE(xc0, long long, 1);
+    TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
+    HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
+    KhFusedParams F;
+    F.rec = R.rec; F.part_off = R.part_off; F.PB = PB; F.New = nw; F.seed = t->seed;
+    F.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST;
+    F.pub = reinterpret_cast<unsigned long long*>(blk);
+    unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);   // 2 x u64 (k_fused_totals)
+    F.maxidx = maxidx;
+    F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
+    F.est = reinterpret_cast<uint32_t*>(blk + sz_pub + 32);                    // 3 x u32
+    F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);                  // KH_NFLAGS x u32
+    F.n_total = n; F.half_max_load = threshold(cap_u >> 1, t->max_lf);
+    { Launch L(t, "k_build_fused");
+      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    { Launch L(t, "k_fused_totals");
+      hipLaunchKernelGGL(k_fused_totals, dim3(1), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
+    { // chunk 0: placed now that the last chunk's run-over is known (one workgroup of the general placement kernel)
+      Launch L(t, "k_fused_tail");
+      hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);
+      HIPCHK(hipMemsetAsync(noff0, 0, 16, t->stream));
+      // list length of partition 0 = count field of pub[0]
+      HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
+      KhRebuildParams T0;
+      memset(&T0, 0, sizeof(T0));
+      T0.Old = KhSlots{nullptr, nullptr, nullptr, 0}; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
+      T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
+      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    const uint64_t fd = t->hpin[0];
+    const uint64_t flast = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
+    const uint32_t* ff = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 64);
+    bool bad = false;
+    for (int i = 0; i < KH_NFLAGS; ++i) bad = bad || ff[i] != 0;
+    if (!bad && capacity_after(t, t->cur.cap, t->lsize, n, fd, flast) == cap_u) {
+      KhSlots old = t->cur;
+      t->cur = nw;
+      retire_slots(t, old);
+      t->min_load = threshold(cap_u, t->min_lf);
+      t->max_load = threshold(cap_u, t->max_lf);
+      t->lsize = fd;
+      *n_new_out = fd;
+      if (mode == INS_UPDATE) {
+        KhDedupParams A;
+        memset(&A, 0, sizeof(A));
+        A.rec = R.rec; A.part_off = R.part_off; A.T = t->cur; A.seed = t->seed; A.table_empty = 0; A.mode = KH_DEDUP_LAST;
+        uint32_t* cn; TAKE(cn, uint32_t, R.nparts);
+        A.cnt_new = cn; A.max_idx_plus1 = totals; A.flags = F.flags; A.count_cap = 0; A.PB = PB;
+        Launch L(t, "k_dedup_assign");
+        KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, A));
+        HIPCHK(hipGetLastError());
+      }
+      return KH_OK;
+    }
+    retire_slots(t, nw);      // speculation failed (duplicates, skew): the buffer becomes the spare, general path below
+  }
   uint32_t* cnt_new; uint64_t* noff; unsigned long long* scal; uint32_t* flags;
   TAKE(cnt_new, uint32_t, R.nparts); TAKE(noff, uint64_t, R.nparts + 1); TAKE(scal, unsigned long long, 4);
   TAKE(flags, uint32_t, KH_NFLAGS);

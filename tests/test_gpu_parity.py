@@ -337,3 +337,60 @@ def test_random_operation_sequences(oracle, kname, cls, kind, seed):
                 g.rehash(b); o.rehash(b)
         check_state(g, o, kind)
     g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+@pytest.mark.parametrize("hname,hid", HASHES)
+def test_bulk_build_into_empty_table_fused_path(oracle, kname, cls, kind, hname, hid):
+    """few duplicates + empty table = the fused bulk-build kernel (de-dup, count, one-deep carry look-back, placement in
+    one launch); 3 % duplicates exercise first-value-wins inside it; compared with the oracle bit for bit"""
+    n = 300_000
+    keys = W.distinct_u64(n, seed=77)
+    keys[::33] = keys[5::33][: len(keys[::33])]            # ~3 % duplicates, first occurrence later or earlier in the stream
+    vals = np.arange(n, dtype=np.uint32)
+    g = cls(128, 0.35, 0.8, hash=hname, seed=43)
+    o = oracle.OracleTable(kind, 128, 0.35, 0.8, hid, 43)
+    g.profile_enable(True)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals)
+    prof = g.profile()
+    assert "k_build_fused" in prof and "k_dedup" not in prof, prof      # the fused launch was taken and accepted
+    check_state(g, o, kind)
+    check_queries(g, o, W.queries_hits_and_misses(keys, 50_000, 0.5))
+    # reducer form through the same kernel
+    g2 = cls(128, 0.35, 0.8, hash=hname, seed=43)
+    assert g2.insert_reduce_plus(dev(keys)) == o.size()
+    uk, cnt = np.unique(keys, return_counts=True)
+    sk, sv = g2.sorted_items()
+    assert np.array_equal(sk, uk) and np.array_equal(sv, cnt.astype(np.uint32))
+    g.close(); g2.close()
+
+
+def test_general_path_when_fused_build_is_disabled():
+    """the same bulk builds through the general path (k_dedup / k_chunk_count / k_chunk_carry / k_chunk_place):
+    a subset of this file re-run in a child process with KH_DISABLE_FUSED_BUILD=1"""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("KH_DISABLE_FUSED_BUILD"):
+        pytest.skip("already inside the child run")
+    env = dict(os.environ, KH_DISABLE_FUSED_BUILD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "test_incremental_batches_host_arrays or test_capacity_rule_edges or test_pairs_layout or test_sentinel"],
+                       env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    # and a distinct-key bulk build that would otherwise take the fused launch
+    code = ("import numpy as np, kmerhash_amd as kh\n"
+            "from kmerhash_amd import workloads as W\n"
+            "from oracle import oracle_py as O\n"
+            "k = W.distinct_u64(300000, seed=77); v = np.arange(len(k), dtype=np.uint32)\n"
+            "g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8); g.profile_enable(True)\n"
+            "o = O.OracleTable(0, 128, 0.35, 0.8)\n"
+            "assert g.insert(k, v) == o.insert(k, v)\n"
+            "p = g.profile(); assert 'k_dedup' in p and 'k_build_fused' not in p, p\n"
+            "assert np.array_equal(g.export_info(), o.export_info())\n"
+            "a, b = g.sorted_items(), o.sorted_items(); assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])\n"
+            "print('general path ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "general path ok" in r.stdout, r.stdout + r.stderr
