@@ -398,6 +398,45 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
   }
 }
 
+// Both partition levels from ONE sweep over the keys: a 65536-bin histogram of the full partition id lives in LDS as
+// 16-bit fields (128 KB, one 1024-lane workgroup per CU).  A field that reaches 0x8000 hands 0x8000 counts to the
+// global counter (exactly one lane observes the crossing), so no field can overflow whatever the key distribution.
+// The second-level histogram pass over the 16-byte records (0.32 ms at 1e8 keys) is not needed any more.
+#define KH_FULLHIST_THREADS 1024
+template <int HASH>
+__global__ __launch_bounds__(KH_FULLHIST_THREADS) void k_part_hist_full(const char* __restrict__ kbase, uint32_t kstride, uint64_t n, uint64_t seed,
+                                                                         uint32_t PB, uint32_t* __restrict__ counts /* [2^PB], zeroed */) {
+  extern __shared__ __align__(16) uint32_t kh_dyn_smem[];     // 2^PB / 2 words
+  const uint32_t words = PB ? (1u << (PB - 1)) : 1u;
+  for (uint32_t i = threadIdx.x; i < words; i += KH_FULLHIST_THREADS) kh_dyn_smem[i] = 0;
+  __syncthreads();
+  const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint64_t b0 = (uint64_t)blockIdx.x * per;
+  const uint64_t b1 = b0 + per < n ? b0 + per : n;
+  for (uint64_t i = b0 + threadIdx.x; i < b1; i += KH_FULLHIST_THREADS) {
+    const uint64_t key = *reinterpret_cast<const uint64_t*>(kbase + i * kstride);
+    const uint32_t q = kh_part_q(kh_hash64<HASH>(key, seed), PB);
+    const uint32_t sh = 16u * (q & 1u);
+    const uint32_t old = atomicAdd(&kh_dyn_smem[q >> 1], 1u << sh);
+    if ((((old >> sh) & 0xFFFFu) + 1u) == 0x8000u) {
+      atomicSub(&kh_dyn_smem[q >> 1], 0x8000u << sh);
+      atomicAdd(&counts[q], 0x8000u);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < words; i += KH_FULLHIST_THREADS) {
+    const uint32_t w = kh_dyn_smem[i];
+    if (w & 0xFFFFu) atomicAdd(&counts[2 * i], w & 0xFFFFu);
+    if (w >> 16) atomicAdd(&counts[2 * i + 1], w >> 16);
+  }
+}
+// segoff[s] = part_off[s * nb2] (s <= nb1): the pass-1 bucket boundaries are every nb2-th partition boundary
+__global__ void k_seg_offsets(const uint64_t* __restrict__ part_off, uint32_t nb1, uint32_t nb2, uint64_t* __restrict__ segoff,
+                              unsigned long long* __restrict__ cur1) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s <= nb1) { const uint64_t v = part_off[(uint64_t)s * nb2]; segoff[s] = v; if (s < nb1) cur1[s] = v; }
+}
+
 // tiles of KH_PART_TILE records that never straddle a segment (second partition pass)
 __global__ void k_make_tiles(const uint64_t* __restrict__ segoff, uint32_t nseg, KhTile* __restrict__ tiles, uint32_t* __restrict__ ntiles_out) {
   __shared__ uint32_t wtot[16];

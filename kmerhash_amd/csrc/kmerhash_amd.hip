@@ -366,19 +366,44 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   const uint32_t nb1 = 1u << B1, nb2 = 1u << B2;
   uint32_t* counts1; uint64_t* off1; unsigned long long* cur1;
   TAKE(counts1, uint32_t, nb1); TAKE(off1, uint64_t, nb1 + 1); TAKE(cur1, unsigned long long, nb1);
-  HIPCHK(hipMemsetAsync(counts1, 0, sizeof(uint32_t) * nb1, t->stream));
   KhPartParams P;
   memset(&P, 0, sizeof(P));
   P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.rec_in = nullptr; P.n = n;
   P.tiles = nullptr; P.ntiles_dev = nullptr; P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
   P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.counts = counts1; P.cursor = cur1;
   P.orec = ar;
-  const uint32_t hist_grid = std::min<uint32_t>(P.ntiles, 1024);
-  { Launch L(t, "k_part_hist");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(hist_grid), dim3(KH_PART_THREADS), nb1 * 4, t->stream, P)); }
-  { Launch L(t, "k_scan");
-    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts1, (uint64_t)nb1, off1); }
-  HIPCHK(hipMemcpyAsync(cur1, off1, sizeof(uint64_t) * nb1, hipMemcpyDeviceToDevice, t->stream));
+  KhTile* tiles = nullptr; uint32_t* ntiles_dev = nullptr; uint32_t* counts2 = nullptr; uint64_t* off2 = nullptr; unsigned long long* cur2 = nullptr;
+  const uint32_t max_tiles = (uint32_t)(n / KH_PART_TILE) + nb1 + 1;
+  if (B2 > 0) {
+    TAKE(tiles, KhTile, max_tiles); TAKE(ntiles_dev, uint32_t, 1);
+    TAKE(counts2, uint32_t, nparts); TAKE(off2, uint64_t, nparts + 1); TAKE(cur2, unsigned long long, nparts);
+    HIPCHK(hipMemsetAsync(counts2, 0, sizeof(uint32_t) * nparts, t->stream));
+  }
+  const bool full_hist = B2 > 0 && PB <= 16;     // 2^16 16-bit bins = 128 KB of LDS
+  if (full_hist) {
+    // one sweep over the keys gives the histogram of the full partition id; both levels' offsets follow from one scan
+    int ncu = 256;
+    hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, t->device);
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ncu, (n + 4095) / 4096));
+    { Launch L(t, "k_part_hist");
+      const size_t smem = (size_t)(nparts / 2) * 4;
+      KH_SWITCH_HASH(t->hash,
+                     if (smem > 65536) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_hist_full<HASH>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                     hipLaunchKernelGGL((k_part_hist_full<HASH>), dim3(grid), dim3(KH_FULLHIST_THREADS), smem, t->stream,
+                                        kbase, kstride, n, t->seed, PB, counts2)); }
+    { Launch L(t, "k_scan");
+      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts2, (uint64_t)nparts, off2); }
+    hipLaunchKernelGGL(k_seg_offsets, dim3((nb1 + 256) / 256), dim3(256), 0, t->stream, off2, nb1, nb2, off1, cur1);
+  } else {
+    HIPCHK(hipMemsetAsync(counts1, 0, sizeof(uint32_t) * nb1, t->stream));
+    const uint32_t hist_grid = std::min<uint32_t>(P.ntiles, 1024);
+    { Launch L(t, "k_part_hist");
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(hist_grid), dim3(KH_PART_THREADS), nb1 * 4, t->stream, P)); }
+    { Launch L(t, "k_scan");
+      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts1, (uint64_t)nb1, off1); }
+    HIPCHK(hipMemcpyAsync(cur1, off1, sizeof(uint64_t) * nb1, hipMemcpyDeviceToDevice, t->stream));
+  }
   { Launch L(t, "k_part_scatter");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
   if (B2 == 0) {
@@ -388,11 +413,6 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     return KH_OK;
   }
   // second pass inside every first-pass segment
-  const uint32_t max_tiles = (uint32_t)(n / KH_PART_TILE) + nb1 + 1;
-  KhTile* tiles; uint32_t* ntiles_dev; uint32_t* counts2; uint64_t* off2; unsigned long long* cur2;
-  TAKE(tiles, KhTile, max_tiles); TAKE(ntiles_dev, uint32_t, 1);
-  TAKE(counts2, uint32_t, nparts); TAKE(off2, uint64_t, nparts + 1); TAKE(cur2, unsigned long long, nparts);
-  HIPCHK(hipMemsetAsync(counts2, 0, sizeof(uint32_t) * nparts, t->stream));
   { Launch L(t, "k_make_tiles");
     hipLaunchKernelGGL(k_make_tiles, dim3(1), dim3(1024), 0, t->stream, off1, nb1, tiles, ntiles_dev); }
   KhPartParams Q = P;
@@ -400,10 +420,12 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   Q.vbase = nullptr; Q.vstride = 0; Q.rec_in = ar;
   Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
   Q.shift = 0; Q.nb = nb2; Q.counts = counts2; Q.cursor = cur2; Q.orec = br;
-  { Launch L(t, "k_part_hist");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); }
-  { Launch L(t, "k_scan");
-    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts2, (uint64_t)nparts, off2); }
+  if (!full_hist) {
+    { Launch L(t, "k_part_hist");
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); }
+    { Launch L(t, "k_scan");
+      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts2, (uint64_t)nparts, off2); }
+  }
   HIPCHK(hipMemcpyAsync(cur2, off2, sizeof(uint64_t) * nparts, hipMemcpyDeviceToDevice, t->stream));
   { Launch L(t, "k_part_scatter");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
