@@ -11,7 +11,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-STREAMING = ("k_part_scatter", "k_part_hist", "k_dedup", "k_chunk_place", "k_chunk_count", "k_gather_new", "k_compact_hits",
+STREAMING = ("k_part_scatter", "k_part_hist", "k_build_fused", "k_dedup", "k_chunk_place", "k_chunk_count", "k_gather_new", "k_compact_hits",
              "k_shard", "k_flag_tile_sums", "k_occupied_flags")
 ks = glob.glob("gpurun_out/prof_%s/*/*_kernel_stats.csv" % tag)
 if ks:
