@@ -8,6 +8,8 @@
 //     -R <repeat_rate>           multiplicity 1..R per key, default 10 (mean 5.5)   (:192-223)
 //     --max_load / --min_load    load factors, default 0.8 / 0.35                    (:1053-1056)
 //     -r <repeats>               timed repeats of the whole sequence (fresh map each), default 1
+//     -F <file>                  replay a dumped input instead of generating one (:241-248): the reference's
+//                                serialize_vector format `size_t elsize(=16), size_t n, pair<uint64,uint32>[n]` (io_utils.hpp:57-103)
 //
 // Phases, each timed on the host clock around the batch call (host vectors in, host vectors out -- the
 // reference's semantics, so the numbers INCLUDE PCIe transfers): insert, find, count, erase, count2.
@@ -18,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -44,6 +47,20 @@ std::vector<pair_t> generate_input(size_t count, size_t repeats) {
   SplitMix sh{29};
   for (size_t i = out.size(); i > 1; --i) std::swap(out[i - 1], out[sh.next() % i]);   // Fisher-Yates
   return out;
+}
+
+// deserialize_vector<std::pair<uint64_t,uint32_t>> (io_utils.hpp:83-103): throws std::logic_error on an element-size mismatch
+std::vector<pair_t> load_input(std::string const& path) {
+  std::FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("cannot open " + path);
+  size_t hdr[2] = {0, 0};
+  if (std::fread(hdr, sizeof(size_t), 2, f) != 2) { std::fclose(f); throw std::runtime_error("truncated header"); }
+  if (hdr[0] != sizeof(pair_t)) { std::fclose(f); throw std::logic_error("input element size not as specified "); }
+  std::vector<pair_t> v(hdr[1]);
+  const size_t got = std::fread(static_cast<void*>(v.data()), sizeof(pair_t), hdr[1], f);
+  std::fclose(f);
+  if (got != hdr[1]) throw std::runtime_error("truncated file");
+  return v;
 }
 
 struct Timer {
@@ -88,7 +105,7 @@ void benchmark_hashmap(std::string const& name, std::vector<pair_t> const& input
 }  // namespace
 
 int main(int argc, char** argv) {
-  std::string map = "robinhood";
+  std::string map = "robinhood", fname;
   size_t N = 100000000, Q = 10, R = 10, reps = 1;
   float max_load = 0.8f, min_load = 0.35f;
   for (int i = 1; i < argc; ++i) {
@@ -98,13 +115,14 @@ int main(int argc, char** argv) {
     else if (a == "-N") N = std::strtoull(need("-N"), nullptr, 10);
     else if (a == "-Q") Q = std::strtoull(need("-Q"), nullptr, 10);
     else if (a == "-R") R = std::strtoull(need("-R"), nullptr, 10);
+    else if (a == "-F") fname = need("-F");
     else if (a == "-r") reps = std::strtoull(need("-r"), nullptr, 10);
     else if (a == "--max_load") max_load = std::strtof(need("--max_load"), nullptr);
     else if (a == "--min_load") min_load = std::strtof(need("--min_load"), nullptr);
-    else { std::fprintf(stderr, "usage: %s [-m robinhood|linearprobe] [-N n] [-Q query_frac] [-R repeat_rate] [-r repeats] [--max_load f] [--min_load f]\n", argv[0]); return 1; }
+    else { std::fprintf(stderr, "usage: %s [-m robinhood|linearprobe] [-N n] [-Q query_frac] [-R repeat_rate] [-r repeats] [-F file] [--max_load f] [--min_load f]\n", argv[0]); return 1; }
   }
   if (Q == 0 || R == 0) return 1;
-  std::vector<pair_t> input = generate_input(N, R);
+  std::vector<pair_t> input = fname.empty() ? generate_input(N, R) : load_input(fname);
   for (size_t r = 0; r < reps; ++r) {
     if (map == "robinhood") benchmark_hashmap<::fsc::hashmap_robinhood_doubling>("robinhood", input, Q, max_load, min_load);
     else if (map == "linearprobe") benchmark_hashmap<::fsc::hashmap_linearprobe_doubling>("linearprobe", input, Q, max_load, min_load);

@@ -815,7 +815,9 @@ kh_status kh_destroy(kh_table* t) {
 
 kh_status kh_set_stream(kh_table* t, void* s) {
   if (!valid(t)) return KH_ERR_INVALID;
-  hipStreamSynchronize(t->stream);
+  if (t->stream == static_cast<hipStream_t>(s)) return KH_OK;     // unchanged: nothing to order
+  hipSetDevice(t->device);
+  hipStreamSynchronize(t->stream);                                   // work already issued stays ordered before the new stream's
   t->stream = static_cast<hipStream_t>(s);
   return KH_OK;
 }

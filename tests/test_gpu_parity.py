@@ -394,3 +394,34 @@ def test_general_path_when_fused_build_is_disabled():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "general path ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_c_abi_argument_errors_and_dump_replay(tmp_path):
+    """bad arguments come back as status codes (no exception crosses the ABI); the C++ driver replays a dump (-F)"""
+    import ctypes as C
+    import os
+    import subprocess
+    from kmerhash_amd import _capi as K, io_utils as IO
+    L = K.lib()
+    h = C.c_void_p()
+    assert L.kh_create(C.byref(h), 0, 8, 4, 1, 43, 128, 0.35, 0.8, 0) == K.KH_OK
+    n = C.c_uint64()
+    assert L.kh_insert(h, None, None, 5, K.KH_MEM_HOST, C.byref(n)) == K.KH_ERR_INVALID
+    assert b"null" in L.kh_last_error(h)
+    assert L.kh_insert(h, None, None, 0, K.KH_MEM_HOST, C.byref(n)) == K.KH_OK and n.value == 0
+    assert L.kh_count(h, None, 3, K.KH_MEM_HOST, None) == K.KH_ERR_INVALID
+    assert L.kh_find_compact(h, None, 3, K.KH_MEM_HOST, None, None, C.byref(n)) == K.KH_ERR_INVALID
+    assert L.kh_size(None, C.byref(n)) == K.KH_ERR_INVALID
+    assert L.kh_create(C.byref(C.c_void_p()), 0, 8, 4, 1, 43, 128, 0.35, 0.8, 99) == K.KH_ERR_INVALID      # no such device
+    assert L.kh_create(C.byref(C.c_void_p()), 5, 8, 4, 1, 43, 128, 0.35, 0.8, 0) == K.KH_ERR_INVALID       # no such kind
+    assert L.kh_destroy(h) == K.KH_OK
+    assert L.kh_release_cached_memory(0) == K.KH_OK
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binp = os.path.join(root, "benchmark", "_benchmark_hashtables")
+    if not os.path.exists(binp):
+        pytest.skip("driver not built (test_cpp_shim builds it)")
+    keys, vals = W.w1_benchmark_hashtables(100_000, seed=5)
+    p = str(tmp_path / "dump.bin")
+    IO.serialize_pairs(keys, vals, p)
+    r = subprocess.run([binp, "-m", "robinhood", "-F", p, "-Q", "10"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "N=100000 distinct=%d" % len(np.unique(keys)) in r.stdout, r.stdout + r.stderr
