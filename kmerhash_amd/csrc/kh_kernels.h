@@ -6,7 +6,9 @@
 // passes, each partition is de-duplicated first-value-wins inside LDS, and every chunk of the new
 // table is then laid out in its canonical Robin Hood order (elements sorted by home bucket, slot =
 // max(home, previous slot + 1)) by one workgroup that histograms the chunk's home buckets in LDS and
-// runs a max-plus scan over them; run-over between chunks is a (max,+) carry scanned across chunks.
+// runs a max-plus scan over them; run-over between chunks is a (max,+) carry.  Bulk builds into an
+// empty table do all of that after the partition in ONE kernel (k_build_fused, one-deep carry
+// look-back); the general path is k_dedup -> k_chunk_count -> k_chunk_carry -> k_chunk_place.
 // Read-only batches (find/count) and erase marking probe the table directly, one query per lane.
 //
 // Wave64 everywhere; no MFMA (integer/indexing path).
@@ -531,6 +533,44 @@ __device__ __forceinline__ uint32_t kh_wave_max(uint32_t v) {
   return v;
 }
 
+enum { KH_DEDUP_FIRST = 0, KH_DEDUP_LAST = 1, KH_DEDUP_PLUS = 2 };
+#define KH_DD_M 2048u            // records staged per de-dup round
+
+// Folds the duplicates among the ns records staged in LDS (lk = keys, liv = idx<<32|val) into one representative per
+// distinct key: the record that claims the key's entry of the 32-bit index set (one ds_cmpst_b32); every other
+// occurrence merges its (idx|val) word into the representative's with one 64-bit LDS atomic -- min = first value wins
+// (the index is the high word), max = last value wins, add = std::plus on the value.  Returns the bit mask of this
+// lane's records (x = it * KH_CHUNK_THREADS + tid) that are representatives.  ns <= KH_DD_M < KH_HS entries: the probe
+// always finds an empty entry.  Caller: set[] zeroed and records staged before (barrier), barrier after.
+__device__ __forceinline__ uint32_t kh_dd_fold(const unsigned long long* lk, unsigned long long* liv, uint32_t* set, uint32_t ns, int mode) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t rep_mask = 0;
+  for (uint32_t x0 = 0, it = 0; x0 < ns; x0 += KH_CHUNK_THREADS, ++it) {
+    const uint32_t x = x0 + tid;
+    if (x < ns) {
+      const unsigned long long key = lk[x];
+      uint32_t slot = (uint32_t)kh_fmix64(key + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
+      for (;;) {
+        uint32_t cur = set[slot];
+        if (cur == 0) {
+          cur = atomicCAS(&set[slot], 0u, x + 1u);
+          if (cur == 0) { rep_mask |= 1u << it; break; }
+        }
+        const uint32_t rep = cur - 1u;
+        if (lk[rep] == key) {
+          const unsigned long long iv = liv[x];
+          if (mode == KH_DEDUP_FIRST) atomicMin(&liv[rep], iv);
+          else if (mode == KH_DEDUP_LAST) atomicMax(&liv[rep], iv);
+          else atomicAdd(&liv[rep], iv & 0xFFFFFFFFull);
+          break;
+        }
+        slot = (slot + 1) & (KH_HS - 1);
+      }
+    }
+  }
+  return rep_mask;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: per-partition first-wins de-duplication in LDS + membership test against the current table.
 // Emits the batch's DISTINCT NEW keys (with the value of their first occurrence).
@@ -553,12 +593,10 @@ struct KhDedupParams {
                                                                  //                  table holds are increased in place, the others are emitted
   uint32_t* flags;
 };
-enum { KH_DEDUP_FIRST = 0, KH_DEDUP_LAST = 1, KH_DEDUP_PLUS = 2 };
 
 // LDS budget 52 KB (3 workgroups per CU): the partition's records are staged in LDS (16 B each) and the hash set
 // holds 32-bit record indices, so a set entry is claimed with one 32-bit CAS and duplicates fold into the claimed
 // record's (idx|val) word with one 64-bit min/max/add.
-#define KH_DD_M 2048u            // records staged per round
 template <int KIND, int HASH>
 __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ unsigned long long lk[KH_DD_M];
@@ -607,31 +645,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
       __syncthreads();
       if (overflow) break;
       const uint32_t ns = R == 1 ? m : n_staged;
-      // fold duplicates into their representative (the record that claimed the set entry)
-      uint32_t rep_mask = 0;          // which of this lane's records are representatives (<= 4 per lane)
-      for (uint32_t x0 = 0, it = 0; x0 < ns; x0 += KH_CHUNK_THREADS, ++it) {
-        const uint32_t x = x0 + tid;
-        if (x < ns) {
-          const unsigned long long key = lk[x];
-          uint32_t slot = (uint32_t)kh_fmix64(key + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
-          for (;;) {     // ns <= KH_DD_M < KH_HS: an empty entry always exists
-            uint32_t cur = set[slot];
-            if (cur == 0) {
-              cur = atomicCAS(&set[slot], 0u, x + 1u);
-              if (cur == 0) { rep_mask |= 1u << it; break; }
-            }
-            const uint32_t rep = cur - 1u;
-            if (lk[rep] == key) {
-              const unsigned long long iv = liv[x];
-              if (P.mode == KH_DEDUP_FIRST) atomicMin(&liv[rep], iv);
-              else if (P.mode == KH_DEDUP_LAST) atomicMax(&liv[rep], iv);
-              else atomicAdd(&liv[rep], iv & 0xFFFFFFFFull);
-              break;
-            }
-            slot = (slot + 1) & (KH_HS - 1);
-          }
-        }
-      }
+      // fold duplicates into their representative; rep_mask: which of this lane's records are representatives
+      const uint32_t rep_mask = kh_dd_fold(lk, liv, set, ns, P.mode);
       __syncthreads();
       // the distinct keys of this class: test membership in the current table, emit the new ones
       uint32_t my_max = 0;
@@ -1026,28 +1041,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = P.rec[beg + i]; lk[i] = rr.x; liv[i] = rr.y; }
   for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
   __syncthreads();
-  uint32_t rep_mask = 0;
-  for (uint32_t x0 = 0, it = 0; x0 < m; x0 += KH_CHUNK_THREADS, ++it) {
-    const uint32_t x = x0 + tid;
-    if (x < m) {
-      const unsigned long long key = lk[x];
-      uint32_t slot = (uint32_t)kh_fmix64(key + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
-      for (;;) {
-        uint32_t cur = set[slot];
-        if (cur == 0) {
-          cur = atomicCAS(&set[slot], 0u, x + 1u);
-          if (cur == 0) { rep_mask |= 1u << it; break; }
-        }
-        const uint32_t rep = cur - 1u;
-        if (lk[rep] == key) {
-          const unsigned long long iv = liv[x];
-          if (P.mode == KH_DEDUP_FIRST) atomicMin(&liv[rep], iv); else atomicAdd(&liv[rep], iv & 0xFFFFFFFFull);
-          break;
-        }
-        slot = (slot + 1) & (KH_HS - 1);
-      }
-    }
-  }
+  const uint32_t rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
   __syncthreads();
   // ---- home counts of the distinct keys (set[] is dead from here on)
   for (uint32_t i = tid; i < 2 * KH_L; i += KH_CHUNK_THREADS) set[i] = 0;
