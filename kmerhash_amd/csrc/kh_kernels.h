@@ -995,7 +995,8 @@ struct KhFusedParams {
   // early give-up on duplicate-heavy batches: after 64 chunks the distinct/record ratio predicts the final size; if even
   // 1.15x of it fits the next smaller capacity the speculation is hopeless, the remaining workgroups return at once
   uint64_t n_total, half_max_load;
-  uint32_t* est;                                         // [0] distinct so far, [1] records so far, [2] abort
+  unsigned long long* est;                               // [0] distinct so far << 32 | records so far (ONE word: the pair must be
+                                                         //     read consistently), [1] abort
   uint32_t* flags;
 };
 template <int KIND, int HASH>
@@ -1018,7 +1019,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   if (tid == 0) {
     s_chunk = blockIdx.x;
     s_max = 0;
-    s_abort = __hip_atomic_load(&P.est[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
   const uint32_t c = s_chunk;
@@ -1096,12 +1097,14 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   // ---- publish / look back
   if (tid == 0) {
     if (c < 64) {     // the first 64 chunks vote on the duplicate ratio (same-address atomics are kept off the other 65 K)
-      const uint32_t sn = atomicAdd(&P.est[0], n_c) + n_c, sm = atomicAdd(&P.est[1], m) + m;
+      const unsigned long long mine = ((unsigned long long)n_c << 32) | m;
+      const unsigned long long tot = atomicAdd(&P.est[0], mine) + mine;      // < 64 * 2048 records: the low word cannot carry
+      const uint32_t sn = (uint32_t)(tot >> 32), sm = (uint32_t)tot;
       if ((c == 63 || (nch < 64 && c == nch - 1)) && sm > 0) {
         const double dhat = (double)P.n_total * (double)sn / (double)sm * 1.15;
         if (dhat <= (double)P.half_max_load) {
           atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
-          __hip_atomic_store(&P.est[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&P.est[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }

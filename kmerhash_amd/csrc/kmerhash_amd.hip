@@ -484,9 +484,11 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);   // 2 x u64 (k_fused_totals)
     F.maxidx = maxidx;
     F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
-    F.est = reinterpret_cast<uint32_t*>(blk + sz_pub + 32);                    // 3 x u32
+    F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);          // 2 x u64
     F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);                  // KH_NFLAGS x u32
-    F.n_total = n; F.half_max_load = threshold(cap_u >> 1, t->max_lf);
+    F.n_total = n;
+    // giving up early only makes sense if a smaller capacity is possible at all (an insert never shrinks the table)
+    F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
     { Launch L(t, "k_build_fused");
       KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     { Launch L(t, "k_fused_totals");
@@ -531,6 +533,11 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
       }
       return KH_OK;
     }
+    if (getenv("KH_DEBUG_FUSED"))
+      fprintf(stderr, "[kmerhash_amd] fused build rejected: n=%llu dnew=%llu cap_u=%llu cap_rule=%llu flags=%u %u %u %u %u est=%u/%u/%u\n", (unsigned long long)n,
+              (unsigned long long)fd, (unsigned long long)cap_u, (unsigned long long)capacity_after(t, t->cur.cap, t->lsize, n, fd, flast), ff[0], ff[1], ff[2], ff[3], ff[4],
+              reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[1], reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[0],
+              reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[2]);
     retire_slots(t, nw);      // speculation failed (duplicates, skew): the buffer becomes the spare, general path below
   }
   uint32_t* cnt_new; uint64_t* noff; unsigned long long* scal; uint32_t* flags;
