@@ -19,14 +19,26 @@ struct Kmer31 {
   uint64_t data;
   Kmer31() : data(0) {}
   explicit Kmer31(uint64_t d) : data(d) {}
+  Kmer31(Kmer31 const& o) : data(o.data) {}                      // user-declared copy operations, like bliss::common::Kmer
+  Kmer31& operator=(Kmer31 const& o) { data = o.data; return *this; }
   bool operator==(Kmer31 const& o) const { return data == o.data; }
   bool operator<(Kmer31 const& o) const { return data < o.data; }
 };
 namespace std { template <> struct hash<Kmer31> { size_t operator()(Kmer31 const& k) const { return k.data; } }; }
 
+// the benchmark's own equality functor (BenchmarkHashTables.cpp:169-180): a global-namespace template, not std::equal_to
+template <class T>
+struct equal_to {
+  using result_type = bool;
+  using first_argument_type = T;
+  using second_argument_type = T;
+  inline constexpr bool operator()(T const& lhs, T const& rhs) const { return lhs == rhs; }
+};
+struct never_equal { bool operator()(uint64_t const&, uint64_t const&) const { return false; } };
+
 template <template <typename, typename, typename, typename, typename> class MAP, typename Key, typename Hash>
 void differential(const char* name, size_t n, bool is_rh) {
-  using Map = MAP<Key, uint32_t, Hash, ::std::equal_to<Key>, ::std::allocator<::std::pair<Key, uint32_t> > >;
+  using Map = MAP<Key, uint32_t, Hash, ::equal_to<Key>, ::std::allocator<::std::pair<Key, uint32_t> > >;
   std::default_random_engine gen(17);
   std::uniform_int_distribution<uint64_t> dist(2, (uint64_t(1) << 62) - 2);
   std::vector<std::pair<Key, uint32_t> > input;
@@ -102,6 +114,15 @@ int main() {
     for (size_t i = 0; i < k.size(); ++i) CHECK(out[i] == h(k[i]));
     CHECK(h(uint64_t(1)) == 0xdbcde6617f85bf2aull);
     CHECK(fsc::hash::murmur<uint64_t>(43)(uint64_t(1)) == 0x252c590efc7e7503ull);
+  }
+  {  // an Equal functor that is not bitwise equality is refused at construction
+    bool threw = false;
+    try { fsc::hashmap_robinhood_doubling<uint64_t, uint32_t, fsc::hash::murmur<uint64_t>, never_equal> bad; }
+    catch (std::invalid_argument&) { threw = true; }
+    CHECK(threw);
+    fsc::hashmap_linearprobe_doubling<uint64_t, uint32_t, fsc::hash::farm<uint64_t> > ok;   // defaults: std::equal_to, 0.2/0.6
+    ok.insert(uint64_t(5), 7u);
+    CHECK(ok.find(uint64_t(5))->second == 7u);
   }
   std::printf("all shim tests passed\n");
   return 0;
