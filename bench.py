@@ -75,6 +75,12 @@ def main():
     ap.add_argument("--chunks", type=int, default=1, help="N>1: pieces of the exchange/insert overlap (1 = exchange, then one bulk insert)")
     args = ap.parse_args()
 
+    # everything libraries write to stdout (RCCL prints a version banner there at communicator creation) goes to stderr,
+    # so that stdout carries exactly ONE line: the JSON result
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import kmerhash_amd as kh
     from kmerhash_amd import dist as khd
@@ -225,7 +231,10 @@ def main():
         }
         if not args.no_cpu_baseline and not distributed:
             out["cpu_baseline"] = cpu_baseline(keys, vals, q)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.destroy_process_group()
 
