@@ -616,38 +616,70 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   const uint32_t chunk = P.PB ? (__brev(q) >> (32 - P.PB)) : 0u;      // partition id = bit-reversed chunk id
   const uint64_t Sc = (uint64_t)chunk * Lc;
   if (m == 0 && !fuse) { if (tid == 0) P.cnt_new[q] = 0; return; }
-  // key classes (by a hash independent of the table's): one round when the partition fits the staging area
-  uint32_t R = m <= KH_DD_M ? 1u : (m + KH_DD_M / 2 - 1) / (KH_DD_M / 2);
+  // The records are streamed through the staging area in tiles: the distinct keys found so far stay at its front
+  // (D of them), the rest is refilled from the stream, folded, and the representatives are compacted to the front
+  // again.  A partition of ANY size and multiplicity (1e7 copies of one k-mer are one key of one partition) therefore
+  // needs one pass over its records as long as its DISTINCT keys fit (<= KH_DD_M - 512); only then are the keys split
+  // into R classes by a hash independent of the table's and the stream is swept once per class.
+  uint32_t R = 1;
+  unsigned long long* tmp = reinterpret_cast<unsigned long long*>(set);      // compaction scratch: KH_HS * 4 B = KH_DD_M * 8 B
+  static_assert(KH_HS * 4 == KH_DD_M * 8, "set[] doubles as the compaction scratch");
   bool done = false;
   while (!done) {
     if (tid == 0) { out_count = 0; overflow = 0; max_idx = 0; }
     if (fuse) for (uint32_t i = tid; i < KH_L / 2; i += KH_CHUNK_THREADS) cnt16[i] = 0;
     for (uint32_t r = 0; r < R; ++r) {
-      for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
-      if (tid == 0) n_staged = 0;
+      uint32_t D = 0, pos = 0, ns = 0, rep_mask = 0;
       __syncthreads();
-      // stage the records of class r
-      for (uint32_t i0 = 0; i0 < m; i0 += KH_CHUNK_THREADS) {
-        const uint32_t i = i0 + tid;
-        bool take = false;
-        unsigned long long key = 0, iv = 0;
-        if (i < m) {
-          const ulonglong2 rr = P.rec[beg + i];
-          key = rr.x; iv = rr.y;
-          take = R == 1 || (uint32_t)((kh_fmix64(key + 0x9E3779B97F4A7C15ull) >> 32) % R) == r;
+      for (;;) {
+        // ---- refill: stream sub-tiles of KH_CHUNK_THREADS records while a whole sub-tile still fits
+        if (tid == 0) n_staged = 0;
+        __syncthreads();
+        do {
+          const uint32_t i = pos + tid;
+          bool take = false;
+          unsigned long long key = 0, iv = 0;
+          if (i < m) {
+            const ulonglong2 rr = P.rec[beg + i];
+            key = rr.x; iv = rr.y;
+            take = R == 1 || (uint32_t)((kh_fmix64(key + 0x9E3779B97F4A7C15ull) >> 32) % R) == r;
+          }
+          const uint32_t x = D + kh_wave_append(take, &n_staged);
+          if (take) { lk[x] = key; liv[x] = iv; }
+          pos += KH_CHUNK_THREADS;
+          __syncthreads();
+          ns = D + n_staged;
+          __syncthreads();        // every lane has read the count before the next sub-tile's appends move it
+        } while (pos < m && ns + KH_CHUNK_THREADS <= KH_DD_M);
+        // ---- fold duplicates into their representative; rep_mask: which of this lane's records are representatives
+        for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+        __syncthreads();
+        rep_mask = kh_dd_fold(lk, liv, set, ns, P.mode);
+        __syncthreads();
+        if (pos >= m) break;                       // stream exhausted: the representatives are this class's distinct keys
+        // ---- compact the representatives to the front (set[] is free again: scratch), then continue with the stream
+        if (tid == 0) n_staged = 0;
+        __syncthreads();
+        uint32_t nx[KH_DD_M / KH_CHUNK_THREADS];
+#pragma unroll
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+          const bool rep = (rep_mask >> it) & 1u;
+          nx[it] = kh_wave_append(rep, &n_staged);
+          if (rep) tmp[nx[it]] = lk[it * KH_CHUNK_THREADS + tid];
         }
-        uint32_t x = R == 1 ? i : kh_wave_append(take, &n_staged);
-        if (take) {
-          if (x < KH_DD_M) { lk[x] = key; liv[x] = iv; }
-          else overflow = 1;
-        }
+        __syncthreads();
+        D = n_staged;
+        for (uint32_t j = tid; j < D; j += KH_CHUNK_THREADS) { const unsigned long long k = tmp[j]; lk[j] = k; }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it)
+          if ((rep_mask >> it) & 1u) tmp[nx[it]] = liv[it * KH_CHUNK_THREADS + tid];
+        __syncthreads();
+        for (uint32_t j = tid; j < D; j += KH_CHUNK_THREADS) { const unsigned long long v = tmp[j]; liv[j] = v; }
+        __syncthreads();
+        if (D + KH_CHUNK_THREADS > KH_DD_M) { if (tid == 0) overflow = 1; __syncthreads(); break; }   // too many distinct keys for one class
       }
-      __syncthreads();
       if (overflow) break;
-      const uint32_t ns = R == 1 ? m : n_staged;
-      // fold duplicates into their representative; rep_mask: which of this lane's records are representatives
-      const uint32_t rep_mask = kh_dd_fold(lk, liv, set, ns, P.mode);
-      __syncthreads();
       // the distinct keys of this class: test membership in the current table, emit the new ones
       uint32_t my_max = 0;
       for (uint32_t x0 = 0, it = 0; x0 < ns; x0 += KH_CHUNK_THREADS, ++it) {
@@ -684,6 +716,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
     if (overflow) { R *= 2; __syncthreads(); if (R > 2 * m + 2) { if (tid == 0) atomicOr(&P.flags[KH_FLAG_INTERNAL], 1u); break; } }
     else done = true;
   }
+  __syncthreads();
   if (tid == 0) {
     P.cnt_new[q] = out_count;
     if (out_count) atomicMax(P.max_idx_plus1, (unsigned long long)max_idx);

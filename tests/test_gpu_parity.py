@@ -425,3 +425,37 @@ def test_c_abi_argument_errors_and_dump_replay(tmp_path):
     IO.serialize_pairs(keys, vals, p)
     r = subprocess.run([binp, "-m", "robinhood", "-F", p, "-Q", "10"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "N=100000 distinct=%d" % len(np.unique(keys)) in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_extreme_multiplicity_and_dense_chunks(oracle, kname, cls, kind):
+    """k-mer counting meets keys that occur millions of times (poly-A ...): all copies of a key are one key of ONE
+    partition, which is streamed through the LDS staging area tile by tile; a chunk denser than the staging area
+    (identity hash, consecutive homes) forces the key-class rounds"""
+    rng = np.random.default_rng(9)
+    heavy = np.array([0x1111, 0xFFFFFFFFFFFFFFFF, 0xABCDEF0123456789], dtype=np.uint64)
+    keys = np.concatenate([np.repeat(heavy, [1_500_000, 400_000, 300_000]), W.distinct_u64(200_000, seed=4)])
+    keys = keys[rng.permutation(len(keys))]
+    vals = np.arange(len(keys), dtype=np.uint32)
+    g = cls(128, 0.35, 0.8)
+    o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals) == 200_003
+    check_state(g, o, kind)
+    g2 = cls(128, 0.35, 0.8)
+    g2.insert_reduce_plus(dev(keys))
+    uk, cnt = np.unique(keys, return_counts=True)
+    sk, sv = g2.sorted_items()
+    assert np.array_equal(sk, uk) and np.array_equal(sv, cnt.astype(np.uint32))
+    g.close(); g2.close()
+    # one chunk holding 1800 consecutive homes (identity hash) + a sparse rest: > 1536 distinct keys in one partition
+    dense = np.uint64(5 * 2048) + np.arange(1800, dtype=np.uint64)
+    sparse = (np.arange(20_000, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(1 << 40)
+    k2 = np.concatenate([dense, sparse, dense[:500]])
+    k2 = k2[rng.permutation(len(k2))]
+    v2 = np.arange(len(k2), dtype=np.uint32)
+    g = cls(128, 0.35, 0.8, hash="identity")
+    o = oracle.OracleTable(kind, 128, 0.35, 0.8, 0, 43)
+    if o.insert(k2, v2) and not o.probe_overflow():
+        assert g.insert(dev(k2), dev(v2)) == o.size()
+        check_state(g, o, kind)
+    g.close()
