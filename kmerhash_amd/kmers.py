@@ -106,3 +106,21 @@ def synthetic_fastq(n_reads, read_len=150, genome_len=1_000_000, seed=7, n_rate=
         s[m] = ord("N")
         out.append(b"@r%d\n" % i + s.tobytes() + b"\n+\n" + b"I" * read_len + b"\n")
     return b"".join(out)
+
+
+def synthetic_read_sequences(n_reads, read_len=150, genome_len=1_000_000, seed=7, n_rate=0.001):
+    """the sequence lines of synthetic_fastq's reads without the FASTQ text around them (vectorised: for large inputs):
+    uint8 array of n_reads lines of read_len bases, each followed by a newline"""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, genome_len, dtype=np.uint8)
+    starts = rng.integers(0, genome_len - read_len, n_reads)
+    rev = rng.integers(0, 2, n_reads).astype(bool)
+    idx = starts[:, None] + np.arange(read_len)[None, :]
+    r = genome[idx]
+    r[rev] = (3 - r[rev])[:, ::-1]
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = np.empty((n_reads, read_len + 1), dtype=np.uint8)
+    out[:, :read_len] = lut[r]
+    out[:, :read_len][rng.random((n_reads, read_len)) < n_rate] = ord("N")
+    out[:, read_len] = 10
+    return out.reshape(-1)
