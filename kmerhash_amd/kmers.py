@@ -113,14 +113,19 @@ def synthetic_read_sequences(n_reads, read_len=150, genome_len=1_000_000, seed=7
     uint8 array of n_reads lines of read_len bases, each followed by a newline"""
     rng = np.random.default_rng(seed)
     genome = rng.integers(0, 4, genome_len, dtype=np.uint8)
-    starts = rng.integers(0, genome_len - read_len, n_reads)
-    rev = rng.integers(0, 2, n_reads).astype(bool)
-    idx = starts[:, None] + np.arange(read_len)[None, :]
-    r = genome[idx]
-    r[rev] = (3 - r[rev])[:, ::-1]
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     out = np.empty((n_reads, read_len + 1), dtype=np.uint8)
-    out[:, :read_len] = lut[r]
-    out[:, :read_len][rng.random((n_reads, read_len)) < n_rate] = ord("N")
+    ar = np.arange(read_len, dtype=np.int32)[None, :]
+    for c0 in range(0, n_reads, 100_000):                      # chunked: the index matrix stays cache/L2 sized
+        c1 = min(n_reads, c0 + 100_000)
+        starts = rng.integers(0, genome_len - read_len, c1 - c0, dtype=np.int32)
+        rev = rng.integers(0, 2, c1 - c0, dtype=np.uint8).astype(bool)
+        r = genome[starts[:, None] + ar]
+        r[rev] = (3 - r[rev])[:, ::-1]
+        blk = out[c0:c1, :read_len]
+        blk[...] = lut[r]
+        n_n = rng.binomial((c1 - c0) * read_len, n_rate)
+        if n_n:
+            blk[rng.integers(0, c1 - c0, n_n), rng.integers(0, read_len, n_n)] = ord("N")
     out[:, read_len] = 10
     return out.reshape(-1)
