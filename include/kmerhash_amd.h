@@ -85,6 +85,17 @@ kh_status kh_insert_pairs(kh_table* t, const void* pairs16 /*[h|d]*/, uint64_t n
  *      hashmap_robinhood.hpp:1274-1284 / hashmap_linearprobe.hpp:895-905 */
 kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted);
 
+/* ---- streamed insert: ONE insert(Iter,Iter) whose pairs arrive in pieces (the multi-GPU exchange delivers them peer by
+ *      peer / chunk by chunk: khmxx::ialltoallv_and_modify, incremental_mxx.hpp:3437-3645, calls insert_no_estimate per
+ *      block).  kh_insert_begin announces the exact total; every kh_insert_feed radix-partitions its piece at once and
+ *      returns without synchronising (device pointers), so that work overlaps the next transfer; kh_insert_end de-duplicates
+ *      and builds once.  The result equals kh_insert of the concatenated pieces in feed order (first value wins, same
+ *      capacity rule).  reduce_plus != 0: kh_insert_reduce_plus semantics (vals may be NULL).  At most 16 feeds; no other
+ *      mutating call on the table between begin and end. */
+kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus);
+kh_status kh_insert_feed(kh_table* t, const void* keys /*[h|d] u64[n]*/, const void* vals /*[h|d] u32[n]*/, uint64_t n, kh_mem where);
+kh_status kh_insert_end(kh_table* t, uint64_t* n_inserted);
+
 /* ---- reducer insert: the Reducer = std::plus form of the reference's batched table,
  *      hashmap_robinhood_offsets_reduction::insert(keys, T(1)) / insert(pairs) (robinhood_offset_hashmap_ptr.hpp:85-97,
  *      2787-2885) as used by dsc::counting_batched_robinhood_map (distributed_batched_robinhood_map.hpp:2542-2543,2633,2899):

@@ -250,6 +250,7 @@ struct KhPartParams {
   const char* kbase; uint32_t kstride;     // input keys (stride 8 = SoA, 16 = pair array)
   const char* vbase; uint32_t vstride;     // first pass: input values (null: every record carries vconst); iv = position<<32 | value
   uint32_t vconst;
+  uint64_t idx_base;                       // first pass: stream position of record 0 (streamed inserts: records fed before)
   const ulonglong2* rec_in;                // later passes: the input records (key, iv); kbase/vbase unused
   uint64_t n;                              // number of input records
   const KhTile* tiles;                     // null: arithmetic tiles of KH_PART_TILE over [0,n), seg 0
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
       if (P.rec_in) { const ulonglong2 rr = P.rec_in[d.beg + i]; key[j] = rr.x; iv[j] = rr.y; }
       else {
         key[j] = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
-        iv[j] = ((unsigned long long)(d.beg + i) << 32) |
+        iv[j] = ((unsigned long long)(P.idx_base + d.beg + i) << 32) |
                 (P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : P.vconst);
       }
       uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
@@ -571,14 +572,42 @@ __device__ __forceinline__ uint32_t kh_dd_fold(const unsigned long long* lk, uns
   return rep_mask;
 }
 
+// The records of one partition may come from several feeds of a streamed insert (kh_insert_begin/feed/end): every feed
+// was partitioned on its own, so partition q is the concatenation of q's slice of every source, in feed order.
+#define KH_MAX_SRC 16
+struct KhSrcSet {
+  const ulonglong2* rec[KH_MAX_SRC];     // partitioned records of source s
+  const uint64_t* off[KH_MAX_SRC];       // [nparts+1] partition offsets inside rec[s]
+  uint32_t n;                            // number of sources (>= 1)
+  const uint64_t* merged_off;            // [nparts+1] sum over the sources of off[s][q]: where partition q's OUTPUT list starts
+};
+// per-workgroup view of partition q: s_beg[s] = first record of the slice in source s, s_cum[s] = records before it
+__device__ __forceinline__ uint32_t kh_src_setup(const KhSrcSet& S, uint32_t q, uint64_t* s_beg, uint32_t* s_cum) {
+  if (threadIdx.x == 0) {
+    uint32_t c = 0;
+    for (uint32_t s = 0; s < S.n; ++s) {
+      const uint64_t b = S.off[s][q];
+      s_beg[s] = b; s_cum[s] = c;
+      c += (uint32_t)(S.off[s][q + 1] - b);
+    }
+    s_cum[S.n] = c;
+  }
+  __syncthreads();
+  return s_cum[S.n];
+}
+__device__ __forceinline__ ulonglong2 kh_src_load(const KhSrcSet& S, const uint64_t* s_beg, const uint32_t* s_cum, uint32_t i) {
+  uint32_t s = 0;
+  while (s + 1 < S.n && i >= s_cum[s + 1]) ++s;
+  return S.rec[s][s_beg[s] + (i - s_cum[s])];
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: per-partition first-wins de-duplication in LDS + membership test against the current table.
 // Emits the batch's DISTINCT NEW keys (with the value of their first occurrence).
 // ---------------------------------------------------------------------------------------------
 struct KhDedupParams {
-  const ulonglong2* rec;                                         // partitioned records (key, idx<<32|val)
-  const uint64_t* part_off;                                      // [nparts+1]
-  uint64_t* nk; uint32_t* nv;                                    // outputs, written at part_off[q] + j
+  KhSrcSet src;                                                  // partitioned records (key, idx<<32|val) of every feed
+  uint64_t* nk; uint32_t* nv;                                    // outputs, written at src.merged_off[q] + j
   uint32_t* cnt_new;                                             // [nparts]
   unsigned long long* max_idx_plus1;                             // max (first-occurrence index + 1) over new keys
   KhSlots T; uint64_t seed;
@@ -605,10 +634,12 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ uint32_t n_staged, out_count, overflow, max_idx;
   __shared__ uint32_t cnt16[KH_L / 2];          // fused chunk count: two 16-bit home counters per word
   __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
+  __shared__ uint64_t s_beg[KH_MAX_SRC];
+  __shared__ uint32_t s_cum[KH_MAX_SRC + 1];
   const uint32_t tid = threadIdx.x;
   const uint32_t q = blockIdx.x;
-  const uint64_t beg = P.part_off[q];
-  const uint32_t m = (uint32_t)(P.part_off[q + 1] - beg);
+  const uint32_t m = kh_src_setup(P.src, q, s_beg, s_cum);
+  const uint64_t beg = P.src.merged_off[q];            // output list of this partition
   const uint64_t mask = P.T.cap - 1;
   const bool fuse = P.count_cap != 0;
   const uint64_t cmask = P.count_cap - 1;
@@ -640,7 +671,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           bool take = false;
           unsigned long long key = 0, iv = 0;
           if (i < m) {
-            const ulonglong2 rr = P.rec[beg + i];
+            const ulonglong2 rr = kh_src_load(P.src, s_beg, s_cum, i);
             key = rr.x; iv = rr.y;
             take = R == 1 || (uint32_t)((kh_fmix64(key + 0x9E3779B97F4A7C15ull) >> 32) % R) == r;
           }
@@ -739,6 +770,12 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
     kh_block_scan_mp(v, s_wtot, &total);
     if (tid == 0) { P.sumA[chunk] = (long long)Sc + total.A; P.sumN[chunk] = total.n; }
   }
+}
+
+// merged_off[q] = sum over the sources of off[s][q] (q <= nparts): start of partition q in the merged (output) order
+__global__ void k_merge_offsets(KhSrcSet S, uint64_t nq_plus1, uint64_t* __restrict__ merged) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq_plus1) { uint64_t v = 0; for (uint32_t s = 0; s < S.n; ++s) v += S.off[s][q]; merged[q] = v; }
 }
 
 // gather the per-partition outputs of k_dedup into one contiguous list (partition order)
@@ -1020,7 +1057,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParam
 #define KH_XB 127u               // bound on a carry-in that may be ignored when publishing early
 #define KH_FSPILL 128u           // run-over slots staged in LDS by the fused kernel
 struct KhFusedParams {
-  const ulonglong2* rec; const uint64_t* part_off; uint32_t PB;
+  KhSrcSet src; uint32_t PB;
   KhSlots New; uint64_t seed; int mode;                  // KH_DEDUP_FIRST or KH_DEDUP_PLUS
   unsigned long long* pub;                               // [nch] zero-initialised: bit63 valid | run-over << 32 | count
   uint64_t* ck0; uint32_t* cv0; uint16_t* homecnt0;      // chunk 0 parked here: distinct keys/values (KH_DD_M), home counts (KH_L)
@@ -1055,10 +1092,11 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  __shared__ uint64_t s_beg[KH_MAX_SRC];
+  __shared__ uint32_t s_cum[KH_MAX_SRC + 1];
   const uint32_t c = s_chunk;
   const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
-  const uint64_t beg = P.part_off[q];
-  const uint32_t m = (uint32_t)(P.part_off[q + 1] - beg);
+  const uint32_t m = kh_src_setup(P.src, q, s_beg, s_cum);
   const uint64_t Sc = (uint64_t)c * KH_L;
   const unsigned long long VALID = 1ull << 63;
   const bool aborted = s_abort != 0;
@@ -1072,7 +1110,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   }
   // ---- de-dup (as k_dedup, single round)
   for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
-  for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = P.rec[beg + i]; lk[i] = rr.x; liv[i] = rr.y; }
+  for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = kh_src_load(P.src, s_beg, s_cum, i); lk[i] = rr.x; liv[i] = rr.y; }
   for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
   __syncthreads();
   const uint32_t rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);

@@ -103,6 +103,14 @@ struct kh_table {
   size_t blk, off;
   uint64_t* hpin;   // pinned host scratch (64 x u64)
   std::string err;
+  // streamed insert (kh_insert_begin / feed / end)
+  struct {
+    bool active, fallback; int mode;
+    uint64_t n_total, fed, cap_u; uint32_t PB;
+    ulonglong2 *tmp, *fin;
+    KhSrcSet S;
+    uint64_t* stage_k; uint32_t* stage_v;
+  } ins;
   bool prof;
   std::vector<ProfRec> recs;
   std::vector<std::pair<std::string, std::pair<double, uint64_t> > > prof_acc;
@@ -324,6 +332,7 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
 
 // rehash(b): hashmap_robinhood.hpp:432-464 / hashmap_linearprobe.hpp:324-349
 kh_status do_rehash(kh_table* t, uint64_t b) {
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   uint64_t n = next_pow2(b);
   if (n == t->cur.cap) return KH_OK;
   if (t->kind == KHK_RH) {
@@ -357,17 +366,20 @@ struct Partitioned {
   ulonglong2* spare;                            // the other record buffer (free for outputs)
 };
 
+// Partitions n input pairs into `fin` (n records); `tmp` (n records) is scratch for the first of two passes.  idx_base =
+// stream position of the first pair (pairs fed before it in a streamed insert).  Asynchronous on the table's stream.
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
-                          uint32_t vconst, uint64_t n, uint32_t PB, Partitioned& out) {
+                          uint32_t vconst, uint64_t n, uint64_t idx_base, uint32_t PB, ulonglong2* tmp, ulonglong2* fin, Partitioned& out) {
   const uint32_t nparts = 1u << PB;
-  ulonglong2 *ar, *br;
-  TAKE(ar, ulonglong2, n); TAKE(br, ulonglong2, n);
+  ulonglong2* ar = nullptr; ulonglong2* br = fin;
   const uint32_t B1 = PB <= 11 ? PB : (PB + 1) / 2, B2 = PB - B1;
   const uint32_t nb1 = 1u << B1, nb2 = 1u << B2;
+  ar = B2 ? tmp : fin;                          // a single pass writes the final buffer directly
   uint32_t* counts1; uint64_t* off1; unsigned long long* cur1;
   TAKE(counts1, uint32_t, nb1); TAKE(off1, uint64_t, nb1 + 1); TAKE(cur1, unsigned long long, nb1);
   KhPartParams P;
   memset(&P, 0, sizeof(P));
+  P.idx_base = idx_base;
   P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.rec_in = nullptr; P.n = n;
   P.tiles = nullptr; P.ntiles_dev = nullptr; P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
   P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.counts = counts1; P.cursor = cur1;
@@ -408,7 +420,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
   if (B2 == 0) {
     out.rec = ar; out.part_off = off1; out.PB = PB; out.nparts = nparts;
-    out.spare = br;
+    out.spare = tmp;
     HIPCHK(hipGetLastError());
     return KH_OK;
   }
@@ -431,7 +443,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
   HIPCHK(hipGetLastError());
   out.rec = br; out.part_off = off2; out.PB = PB; out.nparts = nparts;
-  out.spare = ar;
+  out.spare = tmp;
   return KH_OK;
 }
 
@@ -452,6 +464,10 @@ uint64_t capacity_after(const kh_table* t, uint64_t cap, uint64_t lsize, uint64_
 enum { INS_FIRST = 0, INS_UPDATE = 1, INS_PLUS = 2 };
 bool g_disable_fused = getenv("KH_DISABLE_FUSED_BUILD") != nullptr;   // test hook: force the general path
 
+// second half of an insert: the n pairs have been partitioned (one source per feed); de-dup, capacity decision, build
+kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64_t cap_u, int mode, uint64_t forced_cap,
+                        ulonglong2* spare, uint64_t* n_new_out);
+
 // core of insert/update for one batch of device-resident input (n < 2^32 - 16)
 kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
                       uint64_t n, int mode, uint64_t forced_cap, uint64_t* n_new_out) {
@@ -460,9 +476,23 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   const uint64_t cap_u = forced_cap ? forced_cap : capacity_after(t, t->cur.cap, t->lsize, n, n, n - 1);
   const uint32_t PB = cap_u > KH_L ? log2u(cap_u >> KH_LB) : 0u;
   if (PB > 22) return fail(t, KH_ERR_UNSUPPORTED, "batch would need more than 2^22 partitions");
+  ulonglong2 *tmp, *fin;
+  TAKE(tmp, ulonglong2, n); TAKE(fin, ulonglong2, n);
   Partitioned R;
-  kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, PB, R);
+  kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R);
   if (st != KH_OK) return st;
+  KhSrcSet S;
+  memset(&S, 0, sizeof(S));
+  S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off;
+  return insert_finish(t, S, n, PB, cap_u, mode, forced_cap, tmp, n_new_out);
+}
+
+kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64_t cap_u, int mode, uint64_t forced_cap,
+                        ulonglong2* spare, uint64_t* n_new_out) {
+  *n_new_out = 0;
+  kh_status st = KH_OK;
+  const uint32_t nparts = 1u << PB;
+  struct { uint32_t nparts; } R; R.nparts = nparts;
   // ---- fused bulk build: empty table, moderate load factor, at least two chunks.  Speculates that the capacity the
   // reference's rule yields equals cap_u (true when the batch holds few duplicates); otherwise falls through.
   if (t->lsize == 0 && cap_u >= 2 * (uint64_t)KH_L && t->max_lf <= 0.9f && PB == log2u(cap_u >> KH_LB) && !g_disable_fused) {
@@ -478,7 +508,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
     HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
     KhFusedParams F;
-    F.rec = R.rec; F.part_off = R.part_off; F.PB = PB; F.New = nw; F.seed = t->seed;
+    F.src = S; F.PB = PB; F.New = nw; F.seed = t->seed;
     F.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST;
     F.pub = reinterpret_cast<unsigned long long*>(blk);
     unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);   // 2 x u64 (k_fused_totals)
@@ -524,7 +554,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
       if (mode == INS_UPDATE) {
         KhDedupParams A;
         memset(&A, 0, sizeof(A));
-        A.rec = R.rec; A.part_off = R.part_off; A.T = t->cur; A.seed = t->seed; A.table_empty = 0; A.mode = KH_DEDUP_LAST;
+        A.src = S; A.T = t->cur; A.seed = t->seed; A.table_empty = 0; A.mode = KH_DEDUP_LAST;
         uint32_t* cn; TAKE(cn, uint32_t, R.nparts);
         A.cnt_new = cn; A.max_idx_plus1 = totals; A.flags = F.flags; A.count_cap = 0; A.PB = PB;
         Launch L(t, "k_dedup_assign");
@@ -546,9 +576,9 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   HIPCHK(hipMemsetAsync(scal, 0, sizeof(unsigned long long) * 4, t->stream));
   HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
   KhDedupParams D;
-  D.rec = R.rec; D.part_off = R.part_off;
-  // outputs go into the other record buffer (16 B per input record): keys in its first half, values behind them
-  D.nk = reinterpret_cast<uint64_t*>(R.spare); D.nv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(R.spare) + n * 8);
+  D.src = S;
+  // outputs go into the scratch record buffer (16 B per input record): keys in its first half, values behind them
+  D.nk = reinterpret_cast<uint64_t*>(spare); D.nv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(spare) + n * 8);
   D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
   // speculate that the capacity decided below equals cap_u (true whenever the batch holds few duplicates): then the
   // de-dup kernel already produces the chunk counts and k_chunk_count is skipped
@@ -579,12 +609,12 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     const uint32_t k_new = new_cap > KH_L ? log2u(new_cap >> KH_LB) : 0u;
     const uint64_t* ck = nullptr; const uint32_t* cv = nullptr; const uint64_t* lo = nullptr; const uint32_t* lc = nullptr;
     if (dnew > 0) {
-      if (PB - k_new <= 3) { ck = D.nk; cv = D.nv; lo = R.part_off; lc = cnt_new; }
+      if (PB - k_new <= 3) { ck = D.nk; cv = D.nv; lo = S.merged_off; lc = cnt_new; }
       else {
         uint64_t* gk; uint32_t* gv;
         TAKE(gk, uint64_t, dnew); TAKE(gv, uint32_t, dnew);
         Launch L(t, "k_gather_new");
-        hipLaunchKernelGGL(k_gather_new, dim3(R.nparts), dim3(256), 0, t->stream, R.part_off, noff, D.nk, D.nv, gk, gv);
+        hipLaunchKernelGGL(k_gather_new, dim3(R.nparts), dim3(256), 0, t->stream, S.merged_off, noff, D.nk, D.nv, gk, gv);
         ck = gk; cv = gv; lo = noff; lc = nullptr;
       }
     }
@@ -603,10 +633,39 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   return KH_OK;
 }
 
+// device-resident pairs -> table; the batch is cut only where the reference's one-doubling-per-call rule or the 32-bit
+// record index demands it.  What the arena holds at entry stays (staged input); the rest is reused per sub-batch.
+kh_status insert_device(kh_table* t, const char* kb, uint32_t kstride, const char* vb, uint32_t vstride, uint64_t n, int mode,
+                        uint64_t* total_new_out) {
+  const size_t keep_blk = t->blk, keep_off = t->off;
+  uint64_t total_new = 0, done = 0;
+  kh_status st = KH_OK;
+  while (done < n && st == KH_OK) {
+    // more than one doubling pending (only after set_max_load_factor / an LP shrink): the reference doubles
+    // once per insert() call, so peel single calls until at most one is pending
+    uint64_t take = n - done;
+    if (t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) take = 1;
+    if (take > 0xFFFFFFF0ull) take = 0xFFFFFFF0ull;    // 32-bit record indices
+    t->blk = keep_blk; t->off = keep_off;
+    uint64_t nn = 0;
+    if (take == 1 && t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) {
+      // single call: exactly one doubling, whatever the load afterwards
+      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, 1, mode, t->cur.cap << 1, &nn);
+    } else {
+      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, take, mode, 0, &nn);
+    }
+    total_new += nn;
+    done += take;
+  }
+  *total_new_out = total_new;
+  return st;
+}
+
 kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void* vals, uint32_t vstride, uint64_t n,
                     kh_mem where, int mode, uint64_t* n_inserted) {
   if (n_inserted) *n_inserted = 0;
   if (n && !keys) return fail(t, KH_ERR_INVALID, "null keys");
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
   { const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n ? n : 1, n, n ? n - 1 : 0);
     kh_status ps = arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
@@ -631,26 +690,8 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
       }
     }
   }
-  const size_t keep_blk = t->blk, keep_off = t->off;   // staged input stays; the rest of the arena is reused per sub-batch
-  uint64_t total_new = 0, done = 0;
-  kh_status st = KH_OK;
-  while (done < n && st == KH_OK) {
-    // more than one doubling pending (only after set_max_load_factor / an LP shrink): the reference doubles
-    // once per insert() call, so peel single calls until at most one is pending
-    uint64_t take = n - done;
-    if (t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) take = 1;
-    if (take > 0xFFFFFFF0ull) take = 0xFFFFFFF0ull;    // 32-bit record indices
-    t->blk = keep_blk; t->off = keep_off;
-    uint64_t nn = 0;
-    if (take == 1 && t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) {
-      // single call: exactly one doubling, whatever the load afterwards
-      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, 1, mode, t->cur.cap << 1, &nn);
-    } else {
-      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, take, mode, 0, &nn);
-    }
-    total_new += nn;
-    done += take;
-  }
+  uint64_t total_new = 0;
+  kh_status st = insert_device(t, kb, kstride, vb, vstride, n, mode, &total_new);
   if (st == KH_OK) st = do_reserve(t, t->lsize);   // trailing reserve(lsize) of insert(Iter,Iter) (:672 / :546): a no-op unless size > max_load
   if (st == KH_OK) HIPCHK(hipStreamSynchronize(t->stream));
   arena_consolidate(t);
@@ -734,6 +775,7 @@ kh_status do_find(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint3
 // erase_no_resize over a batch; the caller applies the form-specific resize rule
 kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint64_t* n_erased) {
   *n_erased = 0;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   if (n == 0) return KH_OK;
   if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
@@ -798,6 +840,7 @@ kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t v
   t->min_lf = min_lf; t->max_lf = max_lf; t->lsize = 0;
   t->cur = KhSlots{nullptr, nullptr, nullptr, 0}; t->spare = t->cur;
   t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false;
+  memset(&t->ins, 0, sizeof(t->ins));
   const uint64_t cap = next_pow2(capacity);
   if (alloc_slots(t, cap, t->cur) != KH_OK) { delete t; return KH_ERR_NOMEM; }
   if (hipHostMalloc(reinterpret_cast<void**>(&t->hpin), 64 * sizeof(uint64_t)) != hipSuccess) { free_slots(t, t->cur); delete t; return KH_ERR_NOMEM; }
@@ -870,6 +913,91 @@ kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n,
   if (!t) return KH_ERR_INVALID;
   return do_insert(t, keys, 8, vals, 4, n, where, INS_UPDATE, n_inserted);
 }
+// ---- streamed insert: ONE insert(Iter,Iter) whose input arrives in pieces (the multi-GPU exchange feeds the pieces as
+//      they land; every feed is radix-partitioned right away, asynchronously, so that work overlaps the next transfer)
+kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus) {
+  if (!t) return KH_ERR_INVALID;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is already in progress");
+  HIPCHK(hipSetDevice(t->device));
+  memset(&t->ins, 0, sizeof(t->ins));
+  t->ins.mode = reduce_plus ? INS_PLUS : INS_FIRST;
+  t->ins.n_total = n_total;
+  const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n_total ? n_total : 1, n_total, n_total ? n_total - 1 : 0);
+  { kh_status ps = arena_prepare(t, n_total * 56 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 * (KH_MAX_SRC + 1) +
+                                    (n_total / KH_PART_TILE + 4096 * KH_MAX_SRC) * 16 + (size_t(4) << 20));
+    if (ps != KH_OK) return ps; }
+  const uint32_t PB = cu > KH_L ? log2u(cu >> KH_LB) : 0u;
+  // the one-shot rule evaluation needs at most one pending doubling and 32-bit stream positions; otherwise the pieces are
+  // only collected and inserted by the general entry point at the end
+  t->ins.fallback = n_total == 0 || n_total > 0xFFFFFFF0ull || PB > 22 || t->lsize >= threshold(t->cur.cap << 1, t->max_lf);
+  t->ins.cap_u = cu; t->ins.PB = PB;
+  if (n_total) {
+    if (t->ins.fallback) { TAKE(t->ins.stage_k, uint64_t, n_total); TAKE(t->ins.stage_v, uint32_t, n_total); }
+    else { TAKE(t->ins.tmp, ulonglong2, n_total); TAKE(t->ins.fin, ulonglong2, n_total); }
+  }
+  t->ins.active = true;
+  return KH_OK;
+}
+
+kh_status kh_insert_feed(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where) {
+  if (!t) return KH_ERR_INVALID;
+  if (!t->ins.active) return fail(t, KH_ERR_INVALID, "kh_insert_feed without kh_insert_begin");
+  if (n == 0) return KH_OK;
+  if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
+  if (t->ins.fed + n > t->ins.n_total) return fail(t, KH_ERR_INVALID, "more pairs fed than announced to kh_insert_begin");
+  HIPCHK(hipSetDevice(t->device));
+  const uint64_t* dk; const uint32_t* dv;
+  kh_status st = stage_in<uint64_t>(t, keys, n, where, &dk);
+  if (st == KH_OK) st = stage_in<uint32_t>(t, vals, n, where, &dv);
+  if (st != KH_OK) return st;
+  if (t->ins.fallback) {
+    HIPCHK(hipMemcpyAsync(t->ins.stage_k + t->ins.fed, dk, n * 8, hipMemcpyDeviceToDevice, t->stream));
+    if (dv) HIPCHK(hipMemcpyAsync(t->ins.stage_v + t->ins.fed, dv, n * 4, hipMemcpyDeviceToDevice, t->stream));
+    else HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(t->ins.stage_v + t->ins.fed), t->ins.mode == INS_PLUS ? 1 : 0, n, t->stream));
+  } else {
+    if (t->ins.S.n == KH_MAX_SRC) return fail(t, KH_ERR_UNSUPPORTED, "more than 16 feeds in one streamed insert");
+    Partitioned R;
+    st = partition_batch(t, reinterpret_cast<const char*>(dk), 8, reinterpret_cast<const char*>(dv), 4, t->ins.mode == INS_PLUS ? 1u : 0u,
+                         n, t->ins.fed, t->ins.PB, t->ins.tmp, t->ins.fin + t->ins.fed, R);
+    if (st != KH_OK) return st;
+    t->ins.S.rec[t->ins.S.n] = R.rec; t->ins.S.off[t->ins.S.n] = R.part_off; ++t->ins.S.n;
+  }
+  t->ins.fed += n;
+  return KH_OK;
+}
+
+kh_status kh_insert_end(kh_table* t, uint64_t* n_inserted) {
+  if (n_inserted) *n_inserted = 0;
+  if (!t) return KH_ERR_INVALID;
+  if (!t->ins.active) return fail(t, KH_ERR_INVALID, "kh_insert_end without kh_insert_begin");
+  t->ins.active = false;
+  if (t->ins.fed != t->ins.n_total) return fail(t, KH_ERR_INVALID, "fewer pairs fed than announced to kh_insert_begin");
+  HIPCHK(hipSetDevice(t->device));
+  uint64_t nn = 0;
+  kh_status st = KH_OK;
+  const uint64_t n = t->ins.n_total;
+  if (n) {
+    if (t->ins.fallback) {
+      st = insert_device(t, reinterpret_cast<const char*>(t->ins.stage_k), 8, reinterpret_cast<const char*>(t->ins.stage_v), 4, n, t->ins.mode, &nn);
+    } else {
+      KhSrcSet S = t->ins.S;
+      if (S.n == 1) S.merged_off = S.off[0];
+      else {
+        uint64_t* mo;
+        const uint64_t nq1 = (uint64_t(1) << t->ins.PB) + 1;
+        TAKE(mo, uint64_t, nq1);
+        hipLaunchKernelGGL(k_merge_offsets, dim3((uint32_t)((nq1 + 255) / 256)), dim3(256), 0, t->stream, S, nq1, mo);
+        S.merged_off = mo;
+      }
+      st = insert_finish(t, S, n, t->ins.PB, t->ins.cap_u, t->ins.mode, 0, t->ins.tmp, &nn);
+    }
+  }
+  if (st == KH_OK) st = do_reserve(t, t->lsize);
+  if (st == KH_OK) HIPCHK(hipStreamSynchronize(t->stream));
+  if (n_inserted) *n_inserted = nn;
+  return st;
+}
+
 kh_status kh_insert_reduce_plus(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted) {
   if (!t) return KH_ERR_INVALID;
   return do_insert(t, keys, 8, vals, 4, n, where, INS_PLUS, n_inserted);

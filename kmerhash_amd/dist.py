@@ -112,35 +112,49 @@ class ShardedTable:
 
     # ---- batch operations (collective: every rank calls them) -----------------------------------------
     def insert(self, keys, vals, chunks=1):
-        """insert_p :910-1194.  With chunks > 1 the batch is cut into `chunks` pieces and the exchange of
-        piece k+1 (comm stream) overlaps the local insert of piece k (compute stream) -- the RCCL analogue of
-        khmxx::ialltoallv_and_modify (incremental_mxx.hpp:3437-3645)."""
+        """insert_p :910-1194.  chunks == 1: shard, exchange, one bulk insert.
+        chunks > 1: the RCCL analogue of khmxx::ialltoallv_and_modify (incremental_mxx.hpp:3437-3645): the batch is cut into
+        `chunks` pieces; all pieces are sharded and their counts exchanged first (so the exact number of pairs this rank will
+        receive is known), then the payload of piece i+1 travels on the comm stream while piece i is radix-partitioned into
+        the local table's streamed insert (kh_insert_feed) on the compute stream; kh_insert_end de-duplicates and builds
+        once.  Same result as chunks == 1 with the pieces concatenated piece-major (piece, source rank, position)."""
         n = keys.numel()
         if chunks <= 1 or (self.p == 1 and not FORCE_COLLECTIVES) or not keys.is_cuda:
             rk, rv, _, _ = self._route(keys, vals)
             return self.local.insert(rk, rv)
-        comm = torch.cuda.Stream(device=self.b.torch_device)
-        cur = torch.cuda.current_stream(self.b.torch_device)
         bounds = [n * i // chunks for i in range(chunks + 1)]
-        inserted = 0
-        pending = None
-        for i in range(chunks):
+        parts = []
+        for i in range(chunks):                                   # shard every piece (stable, on the compute stream)
             a, b = bounds[i], bounds[i + 1]
-            comm.wait_stream(cur)
+            parts.append(self.b.shard(keys[a:b], vals[a:b], self.p))
+        # one exchange for all counts: row = destination rank, column = piece
+        host = self._host_staged()
+        cdev = torch.device("cpu") if host else self.b.torch_device
+        sc = torch.tensor([[parts[i][2][r] for i in range(chunks)] for r in range(self.p)], dtype=torch.int64, device=cdev)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc.contiguous(), group=self.group)
+        rc = rc.cpu().tolist()                                     # rc[src][piece]
+        total = sum(sum(row) for row in rc)
+        self.local.insert_begin(total)
+        cur = torch.cuda.current_stream(self.b.torch_device)
+        comm = torch.cuda.Stream(device=self.b.torch_device)
+        comm.wait_stream(cur)
+        keep = []
+        for i in range(chunks):
+            ok, ov, scounts = parts[i]
+            rcounts = [rc[src][i] for src in range(self.p)]
             with torch.cuda.stream(comm):
-                rk, rv, _, _ = self._route(keys[a:b], vals[a:b])
-                rk.record_stream(cur)
-                rv.record_stream(cur)
+                rk = self._a2av(ok, scounts, rcounts)
+                rv = self._a2av(ov, scounts, rcounts)
+                ok.record_stream(comm); ov.record_stream(comm)
+                rk.record_stream(cur); rv.record_stream(cur)
                 ev = torch.cuda.Event()
                 ev.record(comm)
-            if pending is not None:
-                pk, pv, pev = pending
-                cur.wait_event(pev)
-                inserted += self.local.insert(pk, pv)
-            pending = (rk, rv, ev)
-        pk, pv, pev = pending
-        cur.wait_event(pev)
-        inserted += self.local.insert(pk, pv)
+            cur.wait_event(ev)
+            self.local.insert_feed(rk, rv)                         # asynchronous: partitions piece i while piece i+1 travels
+            keep.append((rk, rv))
+        inserted = self.local.insert_end()
+        del keep
         return inserted
 
     def count(self, keys):

@@ -190,6 +190,24 @@ class _HashMapBase:
         self._chk(self._L.kh_update(self._h, kb.ptr, vb.ptr, kb.n, kb.where, C.byref(out)))
         return out.value
 
+    # -- streamed insert: one insert whose pairs arrive in pieces (multi-GPU exchange) ----------------------------
+    def insert_begin(self, n_total, reduce_plus=False):
+        self._chk(self._L.kh_insert_begin(self._h, int(n_total), 1 if reduce_plus else 0))
+
+    def insert_feed(self, keys, vals=None):
+        """partition this piece now (asynchronous for device tensors); the pieces count as one batch in feed order"""
+        kb = _Buf(keys, np.uint64, 8)
+        vb = _Buf(vals, np.uint32, 4) if vals is not None else None
+        if vb is not None and (kb.n != vb.n or kb.where != vb.where):
+            raise ValueError("keys/vals must have equal length and live in the same memory space")
+        self._sync_stream(kb, vb)
+        self._chk(self._L.kh_insert_feed(self._h, kb.ptr, vb.ptr if vb is not None else None, kb.n, kb.where))
+
+    def insert_end(self):
+        out = C.c_uint64()
+        self._chk(self._L.kh_insert_end(self._h, C.byref(out)))
+        return out.value
+
     def insert_reduce_plus(self, keys, vals=None):
         """Reducer = std::plus (k-mer counting when vals is None: every occurrence adds 1).  Returns #new keys.
         reference: hashmap_robinhood_offsets_reduction::insert(keys, T(1)), counting_batched_robinhood_map."""

@@ -459,3 +459,77 @@ def test_extreme_multiplicity_and_dense_chunks(oracle, kname, cls, kind):
         assert g.insert(dev(k2), dev(v2)) == o.size()
         check_state(g, o, kind)
     g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+@pytest.mark.parametrize("cap0", [0, 1, 2, 3, 5, 64, 1000, 5000])
+def test_tiny_and_odd_initial_capacities(oracle, kname, cls, kind, cap0):
+    """ctor capacity is rounded up to a power of two (next_power_of_2; 0 and 1 give 1); tables of 1, 2, 4 ... buckets
+    double on the first calls (max_load = size_t(float(buckets) * 0.8f) is 0 for one bucket)"""
+    keys = W.distinct_u64(40, seed=cap0 + 1)
+    vals = np.arange(40, dtype=np.uint32)
+    g = cls(cap0, 0.35, 0.8)
+    o = oracle.OracleTable(kind, cap0, 0.35, 0.8)
+    assert g.capacity() == o.capacity()
+    for a, b in ((0, 1), (1, 2), (2, 3), (3, 7), (7, 40)):
+        assert g.insert(keys[a:b], vals[a:b]) == o.insert(keys[a:b], vals[a:b])
+        check_state(g, o, kind)
+    check_queries(g, o, np.concatenate([keys[:10], W.distinct_u64(10, seed=99)]))
+    assert g.erase(keys[:35]) == o.erase(keys[:35])
+    check_state(g, o, kind)
+    for k in keys[35:]:
+        assert g.erase_one(int(k)) == o.erase_one(int(k))
+        assert g.capacity() == o.capacity()
+    check_state(g, o, kind)
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+@pytest.mark.parametrize("pieces", [1, 2, 5, 16])
+def test_streamed_insert_equals_one_insert(oracle, kname, cls, kind, pieces):
+    """kh_insert_begin/feed/end: the pieces of one batch, each partitioned on arrival, count as ONE insert(Iter,Iter) in
+    feed order (first value wins across pieces; the capacity rule sees one call sequence)"""
+    rng = np.random.default_rng(pieces)
+    for keys, vals in (W.w1_benchmark_hashtables(150_000, seed=31),                      # duplicates across pieces
+                       (W.distinct_u64(200_000, seed=6), np.arange(200_000, dtype=np.uint32))):   # fused build at the end
+        cuts = np.sort(np.concatenate([[0, len(keys)], rng.integers(0, len(keys), pieces - 1)]))
+        g = cls(128, 0.35, 0.8)
+        o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+        g.insert_begin(len(keys))
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            g.insert_feed(dev(keys[a:b]), dev(vals[a:b])) if (a + b) % 2 else g.insert_feed(keys[a:b], vals[a:b])   # device and host pieces
+        assert g.insert_end() == o.insert(keys, vals)
+        check_state(g, o, kind)
+        # second streamed batch into the now non-empty table, reducer form, values omitted
+        k2 = keys[::3]
+        g.insert_begin(len(k2), reduce_plus=True)
+        h = len(k2) // 2
+        g.insert_feed(dev(k2[:h])); g.insert_feed(dev(k2[h:]))
+        g.insert_end()
+        sk, sv = g.sorted_items()
+        ok, ov = o.sorted_items()
+        uk, cnt = np.unique(k2, return_counts=True)
+        exp = ov.astype(np.uint64)
+        exp[np.searchsorted(ok, uk)] += cnt.astype(np.uint64)
+        assert np.array_equal(sk, ok) and np.array_equal(sv, (exp & 0xFFFFFFFF).astype(np.uint32))
+        g.close()
+
+
+def test_streamed_insert_misuse_is_refused():
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    k = W.distinct_u64(100, seed=1)
+    v = np.arange(100, dtype=np.uint32)
+    with pytest.raises(kh.KhError):
+        g.insert_feed(k, v)                       # no begin
+    g.insert_begin(100)
+    with pytest.raises(kh.KhError):
+        g.insert(k, v)                            # other mutation while streaming
+    with pytest.raises(kh.KhError):
+        g.insert_feed(np.concatenate([k, k]), np.concatenate([v, v]))     # more than announced
+    g.insert_feed(k[:40], v[:40])
+    with pytest.raises(kh.KhError):
+        g.insert_end()                            # fewer than announced
+    assert g.size() == 0
+    g.insert_begin(100); g.insert_feed(k, v)
+    assert g.insert_end() == 100 and g.count(k).all()
+    g.close()
