@@ -890,7 +890,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_count(KhRebuildParam
   __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
   const uint32_t tid = threadIdx.x, c = blockIdx.x;
   const uint32_t Ln = P.New.cap > KH_L ? KH_L : (uint32_t)P.New.cap;
-  const uint64_t Sc = (uint64_t)c * Ln, mask_n = P.New.cap - 1;
+  const uint64_t Sc = (uint64_t)c * Ln;
   for (uint32_t i = tid; i < KH_L; i += KH_CHUNK_THREADS) cnt[i] = 0;
   __syncthreads();
   kh_for_each_old<KIND, HASH>(P, c, &s_emin, [&](uint64_t, uint32_t, uint64_t hn) { atomicAdd(&cnt[hn - Sc], 1u); });
