@@ -1301,7 +1301,8 @@ __global__ void k_occupied_flags(const uint8_t* __restrict__ info, uint64_t cap,
 // multi-GPU sharding: stable partition of (key,value) by rank = hash(key, seed) mod p
 // (distributed_batched_robinhood_map.hpp:513-534 key_to_rank, :632-741 assign_count_permute)
 // ---------------------------------------------------------------------------------------------
-#define KH_SHARD_TILE 2048     // 256 threads x 8 consecutive items
+#define KH_SHARD_THREADS 512
+#define KH_SHARD_TILE (KH_SHARD_THREADS * 8)     // 8 consecutive items per lane; fewer, larger tiles keep the [rank][tile] offset scan short
 #define KH_SHARD_MAXR 64
 template <int HASH>
 __device__ __forceinline__ uint32_t kh_rank_of(uint64_t key, uint64_t seed, uint32_t p, uint32_t pmask) {
@@ -1315,9 +1316,28 @@ __global__ void k_shard_count(const uint64_t* __restrict__ keys, uint64_t n, uin
   if (threadIdx.x < KH_SHARD_MAXR) h[threadIdx.x] = 0;
   __syncthreads();
   uint64_t base = (uint64_t)blockIdx.x * KH_SHARD_TILE;
-  for (uint32_t j = threadIdx.x; j < KH_SHARD_TILE; j += 256) {
-    uint64_t i = base + j;
-    if (i < n) atomicAdd(&h[kh_rank_of<HASH>(keys[i], seed, p, pmask)], 1u);
+  if (p <= 8) {
+    // per-lane counts in 16-bit fields of two 64-bit words, reduced over the wave with shuffles: 8 LDS atomics per wave
+    // instead of one per key on 8 hot bins
+    unsigned long long c0 = 0, c1 = 0;
+    for (uint32_t j = threadIdx.x; j < KH_SHARD_TILE; j += KH_SHARD_THREADS) {
+      const uint64_t i = base + j;
+      if (i < n) {
+        const uint32_t r = kh_rank_of<HASH>(keys[i], seed, p, pmask);
+        if (r < 4) c0 += 1ull << (16 * r); else c1 += 1ull << (16 * (r - 4));
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) { c0 += __shfl_down(c0, off, 64); c1 += __shfl_down(c1, off, 64); }
+    if ((threadIdx.x & 63) == 0)
+      for (uint32_t r = 0; r < p; ++r) {
+        const uint32_t c = (uint32_t)(((r < 4 ? c0 : c1) >> (16 * (r & 3))) & 0xFFFFu);
+        if (c) atomicAdd(&h[r], c);
+      }
+  } else {
+    for (uint32_t j = threadIdx.x; j < KH_SHARD_TILE; j += KH_SHARD_THREADS) {
+      uint64_t i = base + j;
+      if (i < n) atomicAdd(&h[kh_rank_of<HASH>(keys[i], seed, p, pmask)], 1u);
+    }
   }
   __syncthreads();
   if (threadIdx.x < p) tile_counts[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -1327,7 +1347,7 @@ __global__ void k_shard_scatter(const uint64_t* __restrict__ keys, const uint32_
                                 uint32_t p, uint32_t pmask, const uint64_t* __restrict__ tile_off /* [p][ntiles] exclusive */,
                                 uint32_t ntiles, uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
   // stable: lane t owns items [8t, 8t+8) of the tile; per rank, an exclusive scan over lanes gives the order
-  __shared__ uint32_t wtot[4][KH_SHARD_MAXR];
+  __shared__ uint32_t wtot[KH_SHARD_THREADS / 64][KH_SHARD_MAXR];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint64_t base = (uint64_t)blockIdx.x * KH_SHARD_TILE + (uint64_t)tid * 8;
   uint64_t key[8]; uint32_t rk[8];
@@ -1366,13 +1386,13 @@ __global__ void k_shard_scatter(const uint64_t* __restrict__ keys, const uint32_
 // 16-bit fields of two 64-bit words through a single wave scan -- and the tile is staged in LDS in (rank, input
 // order) so that the write-out is coalesced.  Stable, like the generic kernel.
 template <int HASH>
-__global__ __launch_bounds__(256) void k_shard_scatter8(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n,
+__global__ __launch_bounds__(KH_SHARD_THREADS) void k_shard_scatter8(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n,
                                                           uint64_t seed, uint32_t p, uint32_t pmask,
                                                           const uint64_t* __restrict__ tile_off /* [p][ntiles] exclusive */,
                                                           uint32_t ntiles, uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
   __shared__ uint64_t lk[KH_SHARD_TILE];
   __shared__ uint32_t lv[KH_SHARD_TILE];
-  __shared__ unsigned long long wtot[4][2];
+  __shared__ unsigned long long wtot[KH_SHARD_THREADS / 64][2];
   __shared__ uint32_t rank_off[9];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint64_t tbase = (uint64_t)blockIdx.x * KH_SHARD_TILE;
@@ -1399,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_shard_scatter8(const uint64_t* __restri
   if (lane == 63) { wtot[wid][0] = i0; wtot[wid][1] = i1; }
   __syncthreads();
   unsigned long long e0 = i0 - c0, e1 = i1 - c1, t0 = 0, t1 = 0;
-  for (uint32_t w = 0; w < 4; ++w) {
+  for (uint32_t w = 0; w < KH_SHARD_THREADS / 64; ++w) {
     if (w < wid) { e0 += wtot[w][0]; e1 += wtot[w][1]; }
     t0 += wtot[w][0]; t1 += wtot[w][1];
   }
@@ -1423,7 +1443,7 @@ __global__ __launch_bounds__(256) void k_shard_scatter8(const uint64_t* __restri
     }
   }
   __syncthreads();
-  for (uint32_t s = tid; s < tile_len; s += 256) {
+  for (uint32_t s = tid; s < tile_len; s += KH_SHARD_THREADS) {
     uint32_t r = 0;
 #pragma unroll
     for (uint32_t k = 1; k < 8; ++k) r += (s >= rank_off[k]) ? 1u : 0u;

@@ -1150,12 +1150,12 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64
   const uint64_t m = (uint64_t)p * ntiles;
   HIPCHK(pool_alloc(device, m * 4, reinterpret_cast<void**>(&tc)));
   if (pool_alloc(device, (m + 1) * 8, reinterpret_cast<void**>(&toff)) != hipSuccess) { pool_free(device, tc); return KH_ERR_NOMEM; }
-  KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_count<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, n, seed, p, pmask, tc, ntiles));
+  KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_count<HASH>), dim3(ntiles), dim3(KH_SHARD_THREADS), 0, stream, keys, n, seed, p, pmask, tc, ntiles));
   hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, stream, tc, m, toff);
   if (p <= 8) {
-    KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter8<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
+    KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter8<HASH>), dim3(ntiles), dim3(KH_SHARD_THREADS), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
   } else {
-    KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter<HASH>), dim3(ntiles), dim3(256), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
+    KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter<HASH>), dim3(ntiles), dim3(KH_SHARD_THREADS), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
   }
   std::vector<uint64_t> ends(p + 1);
   hipError_t e = hipGetLastError();
