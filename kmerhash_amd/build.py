@@ -8,6 +8,7 @@ SRC = os.path.join(HERE, "csrc", "kmerhash_amd.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "kh_kernels.h"), os.path.join(HERE, "csrc", "kh_hash.h"),
         os.path.join(HERE, "..", "include", "kmerhash_amd.h")]
 LIB = os.path.join(HERE, "libkmerhash_amd.so")
+RES = os.path.join(HERE, "kernel_resources.json")      # per-kernel registers / LDS / occupancy reported by the compiler
 
 
 def hipcc():
@@ -29,11 +30,40 @@ def build_library(force=False, verbose=False):
     if not force and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-comment", "-o", LIB, SRC]
+           "-Wno-unused-value", "-Wno-comment", "-Rpass-analysis=kernel-resource-usage", "-o", LIB, SRC]
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    p = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
+    other = [l for l in p.stderr.splitlines() if "kernel-resource-usage" not in l]
+    if p.returncode != 0 or verbose:
+        print("\n".join(other))
+    if p.returncode != 0:
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+    _write_resources(p.stderr)
     return LIB
+
+
+def _write_resources(remarks):
+    """kernel_resources.json: {mangled kernel name: {"VGPRs":..,"LDS":..,"Occupancy":..,"Scratch":..}} from the compiler's
+    -Rpass-analysis=kernel-resource-usage remarks (tests/test_kernel_resources.py guards the occupancy-critical kernels)"""
+    import json
+    import re
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark:\s+(.*?)\s+\[-Rpass-analysis", line)
+        if not m:
+            continue
+        body = m.group(1).strip()
+        if body.startswith("Function Name:"):
+            cur = out.setdefault(body.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in body:
+            k, v = body.split(":", 1)
+            k = {"VGPRs": "VGPRs", "TotalSGPRs": "SGPRs", "ScratchSize [bytes/lane]": "Scratch", "Occupancy [waves/SIMD]": "Occupancy",
+                 "LDS Size [bytes/block]": "LDS", "VGPRs Spill": "VGPRSpill", "SGPRs Spill": "SGPRSpill"}.get(k.strip())
+            if k:
+                cur[k] = int(v.strip())
+    with open(RES, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":

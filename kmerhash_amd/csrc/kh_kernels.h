@@ -581,24 +581,44 @@ struct KhSrcSet {
   uint32_t n;                            // number of sources (>= 1)
   const uint64_t* merged_off;            // [nparts+1] sum over the sources of off[s][q]: where partition q's OUTPUT list starts
 };
-// per-workgroup view of partition q: s_beg[s] = first record of the slice in source s, s_cum[s] = records before it
-__device__ __forceinline__ uint32_t kh_src_setup(const KhSrcSet& S, uint32_t q, uint64_t* s_beg, uint32_t* s_cum) {
-  if (threadIdx.x == 0) {
-    uint32_t c = 0;
-    for (uint32_t s = 0; s < S.n; ++s) {
-      const uint64_t b = S.off[s][q];
-      s_beg[s] = b; s_cum[s] = c;
-      c += (uint32_t)(S.off[s][q + 1] - b);
-    }
-    s_cum[S.n] = c;
+// per-workgroup view of partition q.  One source (every plain insert): the slice is addressed directly through a
+// wave-uniform pointer, no LDS and no barrier.  Several sources: s_ptr[s] = rec[s] + (first record of the slice) - (records
+// of the partition before it), s_cum[s] = records before it, so that record i of the partition is s_ptr[s][i] for the s
+// with s_cum[s] <= i < s_cum[s+1]; the pointer table lives in LDS (a per-lane index into the kernel arguments would cost
+// a dependent global load per record).
+struct KhSrcView {
+  const ulonglong2* one;                 // != nullptr: single source, slice start
+  uint32_t m;                            // records of the partition
+  uint32_t n;                            // sources
+};
+__device__ __forceinline__ KhSrcView kh_src_setup(const KhSrcSet& S, uint32_t q, const ulonglong2** s_ptr, uint32_t* s_cum) {
+  KhSrcView V;
+  V.n = S.n;
+  if (S.n == 1) {
+    const uint64_t b = S.off[0][q];
+    V.one = S.rec[0] + b;
+    V.m = (uint32_t)(S.off[0][q + 1] - b);
+    return V;
+  }
+  if (threadIdx.x < 64) {
+    const uint32_t s = threadIdx.x;
+    uint64_t b = 0; uint32_t cnt = 0;
+    if (s < S.n) { b = S.off[s][q]; cnt = (uint32_t)(S.off[s][q + 1] - b); }
+    uint32_t inc = cnt;
+    for (int o = 1; o < KH_MAX_SRC; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((int)s >= o) inc += t; }
+    if (s < S.n) { s_cum[s] = inc - cnt; s_ptr[s] = S.rec[s] + b - (inc - cnt); }
+    if (s == S.n - 1) s_cum[S.n] = inc;
   }
   __syncthreads();
-  return s_cum[S.n];
+  V.one = nullptr;
+  V.m = s_cum[S.n];
+  return V;
 }
-__device__ __forceinline__ ulonglong2 kh_src_load(const KhSrcSet& S, const uint64_t* s_beg, const uint32_t* s_cum, uint32_t i) {
+__device__ __forceinline__ ulonglong2 kh_src_load(const KhSrcView& V, const ulonglong2* const* s_ptr, const uint32_t* s_cum, uint32_t i) {
+  if (V.one) return V.one[i];
   uint32_t s = 0;
-  while (s + 1 < S.n && i >= s_cum[s + 1]) ++s;
-  return S.rec[s][s_beg[s] + (i - s_cum[s])];
+  while (s + 1 < V.n && i >= s_cum[s + 1]) ++s;
+  return s_ptr[s][i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -634,11 +654,12 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ uint32_t n_staged, out_count, overflow, max_idx;
   __shared__ uint32_t cnt16[KH_L / 2];          // fused chunk count: two 16-bit home counters per word
   __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
-  __shared__ uint64_t s_beg[KH_MAX_SRC];
+  __shared__ const ulonglong2* s_ptr[KH_MAX_SRC];
   __shared__ uint32_t s_cum[KH_MAX_SRC + 1];
   const uint32_t tid = threadIdx.x;
   const uint32_t q = blockIdx.x;
-  const uint32_t m = kh_src_setup(P.src, q, s_beg, s_cum);
+  const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
+  const uint32_t m = V.m;
   const uint64_t beg = P.src.merged_off[q];            // output list of this partition
   const uint64_t mask = P.T.cap - 1;
   const bool fuse = P.count_cap != 0;
@@ -671,7 +692,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           bool take = false;
           unsigned long long key = 0, iv = 0;
           if (i < m) {
-            const ulonglong2 rr = kh_src_load(P.src, s_beg, s_cum, i);
+            const ulonglong2 rr = kh_src_load(V, s_ptr, s_cum, i);
             key = rr.x; iv = rr.y;
             take = R == 1 || (uint32_t)((kh_fmix64(key + 0x9E3779B97F4A7C15ull) >> 32) % R) == r;
           }
@@ -1076,7 +1097,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   __shared__ uint32_t set[KH_HS];               // de-dup index set, later cnt/fill = set[0..L) and start = set[L..2L)
   // the chunk image is kept as 16-bit indices into the staged records (0xFFFF = empty slot): 4.3 KB instead of the
   // 28 KB of a (key, value, info) image, which keeps the kernel at 53.7 KB of LDS = 3 workgroups per CU
-  __shared__ uint16_t simg[KH_L + KH_FSPILL];
+  __shared__ __align__(8) uint16_t simg[KH_L + KH_FSPILL];
   __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
   __shared__ uint32_t s_chunk, s_x, s_max, s_abort;
   __shared__ long long s_pend;
@@ -1092,11 +1113,15 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  __shared__ uint64_t s_beg[KH_MAX_SRC];
-  __shared__ uint32_t s_cum[KH_MAX_SRC + 1];
+  // the source table of a streamed insert lives in simg[] until the records are staged: every byte of LDS counts here
+  // (53.7 KB = three workgroups per CU; 200 bytes more and only two fit, which costs 45% of the kernel's throughput)
+  const ulonglong2** s_ptr = reinterpret_cast<const ulonglong2**>(simg);
+  uint32_t* s_cum = reinterpret_cast<uint32_t*>(simg) + 2 * KH_MAX_SRC;
+  static_assert((KH_L + KH_FSPILL) * 2 >= KH_MAX_SRC * 8 + (KH_MAX_SRC + 1) * 4, "source table fits the image array");
   const uint32_t c = s_chunk;
   const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
-  const uint32_t m = kh_src_setup(P.src, q, s_beg, s_cum);
+  const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
+  const uint32_t m = V.m;
   const uint64_t Sc = (uint64_t)c * KH_L;
   const unsigned long long VALID = 1ull << 63;
   const bool aborted = s_abort != 0;
@@ -1110,7 +1135,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   }
   // ---- de-dup (as k_dedup, single round)
   for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
-  for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = kh_src_load(P.src, s_beg, s_cum, i); lk[i] = rr.x; liv[i] = rr.y; }
+  for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = kh_src_load(V, s_ptr, s_cum, i); lk[i] = rr.x; liv[i] = rr.y; }
+  if (V.n > 1) __syncthreads();       // the source table (in simg[]) has been read by every lane
   for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
   __syncthreads();
   const uint32_t rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
