@@ -72,7 +72,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="w2", choices=["w2", "w1"],
                     help="w2 = configs[1] (default, the metric's workload); w1 = benchmark_hashtables shape (x5.5 multiplicity), informational")
-    ap.add_argument("--chunks", type=int, default=1, help="N>1: pieces of the exchange/insert overlap (1 = exchange, then one bulk insert)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="N>1: pieces of the pipelined exchange/insert (permute, xGMI transfer and radix partition of successive pieces "
+                         "overlap); 1 = exchange, then one bulk insert; 0 = auto (4 when N>1: the exchange is link-bound at every N)")
     args = ap.parse_args()
 
     # everything libraries write to stdout (RCCL prints a version banner there at communicator creation) goes to stderr,
@@ -89,6 +91,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("KH_DIST_FORCE_COLLECTIVES", "0") == "1"   # rehearsal of the N>1 path on one GPU
+    if args.chunks <= 0:
+        args.chunks = 4 if world > 1 else 1
     if distributed and "RANK" not in os.environ:
         os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
     if distributed:

@@ -136,10 +136,10 @@ kh_status kh_hash_batch(kh_hash hash, uint64_t seed, const void* keys, uint64_t 
 /* ---- key-space sharding for the multi-GPU layer: rank = hash(key, seed) & (p-1) (p power of two) or % p
  *      (distributed_batched_robinhood_map.hpp:513-534,632-741 assign_count_permute).  Device buffers only.
  *      out_* receive the pairs grouped by destination rank (rank 0 first, input order kept inside a rank);
- *      counts_host[p] receives the per-rank element counts. */
+ *      counts_host[p] receives the per-rank element counts.  out_keys_dev == NULL: count only (nothing is permuted). */
 kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t nranks,
                            const uint64_t* keys_dev, const uint32_t* vals_dev /* may be NULL */, uint64_t n,
-                           uint64_t* out_keys_dev, uint32_t* out_vals_dev /* may be NULL */,
+                           uint64_t* out_keys_dev /* may be NULL */, uint32_t* out_vals_dev /* may be NULL */,
                            uint64_t* counts_host, int device, void* hip_stream);
 
 /* ---- k-mer generation front end (BenchmarkKmerCounter.cpp:1655-1706 reads sequences through kmerind's

@@ -1141,7 +1141,7 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64
   if (p == 0 || p > KH_SHARD_MAXR || !counts_host || (int)hash < 0 || (int)hash > 3) return KH_ERR_INVALID;
   for (uint32_t r = 0; r < p; ++r) counts_host[r] = 0;
   if (n == 0) return KH_OK;
-  if (!keys || !out_keys || (vals && !out_vals)) return KH_ERR_INVALID;
+  if (!keys || (out_keys && vals && !out_vals)) return KH_ERR_INVALID;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(device));
   const uint32_t ntiles = (uint32_t)((n + KH_SHARD_TILE - 1) / KH_SHARD_TILE);
@@ -1152,7 +1152,9 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64
   if (pool_alloc(device, (m + 1) * 8, reinterpret_cast<void**>(&toff)) != hipSuccess) { pool_free(device, tc); return KH_ERR_NOMEM; }
   KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_count<HASH>), dim3(ntiles), dim3(KH_SHARD_THREADS), 0, stream, keys, n, seed, p, pmask, tc, ntiles));
   hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, stream, tc, m, toff);
-  if (p <= 8) {
+  if (!out_keys) {
+    // count only: the caller sizes the exchange before it permutes (pipelined multi-GPU insert)
+  } else if (p <= 8) {
     KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter8<HASH>), dim3(ntiles), dim3(KH_SHARD_THREADS), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));
   } else {
     KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_scatter<HASH>), dim3(ntiles), dim3(KH_SHARD_THREADS), 0, stream, keys, vals, n, seed, p, pmask, toff, ntiles, out_keys, out_vals));

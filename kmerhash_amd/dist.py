@@ -60,6 +60,15 @@ class GpuBackend:
             raise self.K.KhError(st, "kh_shard_permute")
         return ok, ov, [int(c) for c in counts]
 
+    def shard_counts(self, keys, p):
+        """counts[p] of shard() without permuting anything"""
+        counts = (self.C.c_uint64 * p)()
+        st = self.K.lib().kh_shard_permute(self.dist_hash, self.dist_seed, p, keys.data_ptr(), None, keys.numel(), None, None,
+                                           counts, self.device, torch.cuda.current_stream(self.device).cuda_stream)
+        if st != self.K.KH_OK:
+            raise self.K.KhError(st, "kh_shard_permute (count only)")
+        return [int(c) for c in counts]
+
     def empty(self, n, dtype):
         return torch.empty(n, dtype=dtype, device=self.torch_device)
 
@@ -113,24 +122,23 @@ class ShardedTable:
     # ---- batch operations (collective: every rank calls them) -----------------------------------------
     def insert(self, keys, vals, chunks=1):
         """insert_p :910-1194.  chunks == 1: shard, exchange, one bulk insert.
-        chunks > 1: the RCCL analogue of khmxx::ialltoallv_and_modify (incremental_mxx.hpp:3437-3645): the batch is cut into
-        `chunks` pieces; all pieces are sharded and their counts exchanged first (so the exact number of pairs this rank will
-        receive is known), then the payload of piece i+1 travels on the comm stream while piece i is radix-partitioned into
-        the local table's streamed insert (kh_insert_feed) on the compute stream; kh_insert_end de-duplicates and builds
-        once.  Same result as chunks == 1 with the pieces concatenated piece-major (piece, source rank, position)."""
+        chunks > 1: the RCCL analogue of khmxx::ialltoallv_and_modify (incremental_mxx.hpp:3437-3645).  The batch is cut into
+        `chunks` pieces.  A count-only pass over every piece and ONE exchange of all the counts tell each rank exactly how
+        many pairs it will receive, piece by piece.  Then piece i is permuted on the compute stream, its payload travels on
+        the comm stream, and piece i-1 -- already landed -- is radix-partitioned into the local table's streamed insert
+        (kh_insert_feed) on the compute stream meanwhile; kh_insert_end de-duplicates and builds once.  xGMI transfers and
+        HBM-bound kernels use different resources, so permute + partition hide under the exchange (or the other way round).
+        Same result as chunks == 1 with the pieces concatenated piece-major (piece, source rank, position)."""
         n = keys.numel()
         if chunks <= 1 or (self.p == 1 and not FORCE_COLLECTIVES) or not keys.is_cuda:
             rk, rv, _, _ = self._route(keys, vals)
             return self.local.insert(rk, rv)
         bounds = [n * i // chunks for i in range(chunks + 1)]
-        parts = []
-        for i in range(chunks):                                   # shard every piece (stable, on the compute stream)
-            a, b = bounds[i], bounds[i + 1]
-            parts.append(self.b.shard(keys[a:b], vals[a:b], self.p))
-        # one exchange for all counts: row = destination rank, column = piece
+        # per-piece destination counts (count-only pass), one exchange for all of them: row = destination rank, column = piece
+        sc_piece = [self.b.shard_counts(keys[bounds[i]:bounds[i + 1]], self.p) for i in range(chunks)]
         host = self._host_staged()
         cdev = torch.device("cpu") if host else self.b.torch_device
-        sc = torch.tensor([[parts[i][2][r] for i in range(chunks)] for r in range(self.p)], dtype=torch.int64, device=cdev)
+        sc = torch.tensor([[sc_piece[i][r] for i in range(chunks)] for r in range(self.p)], dtype=torch.int64, device=cdev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc.contiguous(), group=self.group)
         rc = rc.cpu().tolist()                                     # rc[src][piece]
@@ -138,11 +146,12 @@ class ShardedTable:
         self.local.insert_begin(total)
         cur = torch.cuda.current_stream(self.b.torch_device)
         comm = torch.cuda.Stream(device=self.b.torch_device)
-        comm.wait_stream(cur)
-        keep = []
+        keep, landed = [], None
         for i in range(chunks):
-            ok, ov, scounts = parts[i]
+            a, b = bounds[i], bounds[i + 1]
+            ok, ov, scounts = self.b.shard(keys[a:b], vals[a:b], self.p)     # compute stream (stable permutation)
             rcounts = [rc[src][i] for src in range(self.p)]
+            comm.wait_stream(cur)
             with torch.cuda.stream(comm):
                 rk = self._a2av(ok, scounts, rcounts)
                 rv = self._a2av(ov, scounts, rcounts)
@@ -150,9 +159,13 @@ class ShardedTable:
                 rk.record_stream(cur); rv.record_stream(cur)
                 ev = torch.cuda.Event()
                 ev.record(comm)
-            cur.wait_event(ev)
-            self.local.insert_feed(rk, rv)                         # asynchronous: partitions piece i while piece i+1 travels
-            keep.append((rk, rv))
+            if landed is not None:                                 # piece i-1: partition it while piece i travels
+                cur.wait_event(landed[0])
+                self.local.insert_feed(landed[1], landed[2])
+            landed = (ev, rk, rv)
+            keep.append((ok, ov, rk, rv))
+        cur.wait_event(landed[0])
+        self.local.insert_feed(landed[1], landed[2])
         inserted = self.local.insert_end()
         del keep
         return inserted

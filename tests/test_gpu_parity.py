@@ -249,6 +249,7 @@ def test_shard_permute_is_stable_partition_by_rank(oracle, p):
     r = (oracle.hash_batch(1, DIST_SEED, keys) % np.uint64(p)).astype(np.int64)
     order = np.argsort(r, kind="stable")
     assert counts == np.bincount(r, minlength=p).tolist()
+    assert be.shard_counts(dev(keys), p) == counts            # count-only mode (out_keys == NULL)
     assert np.array_equal(host(ok, np.uint64), keys[order])
     assert np.array_equal(host(ov, np.uint32), vals[order])
     be.table.close()

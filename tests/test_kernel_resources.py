@@ -1,0 +1,31 @@
+"""Occupancy guard for the LDS-heavy kernels of the insert path (CPU test: reads the compiler's resource report that
+kmerhash_amd/build.py writes next to the library).  k_build_fused / k_dedup / k_chunk_place are sized to the byte for three
+512-lane workgroups per CU (6 waves per SIMD): 200 bytes of LDS more once cost 45% of k_build_fused's throughput."""
+import json
+import os
+
+import pytest
+
+from kmerhash_amd import build as B
+
+
+@pytest.fixture(scope="module")
+def resources():
+    B.build_library()
+    if not os.path.exists(B.RES):
+        B.build_library(force=True)
+    return json.load(open(B.RES))
+
+
+def test_no_scratch_no_spills(resources):
+    assert len(resources) > 50
+    for name, r in resources.items():
+        assert r.get("Scratch", 0) == 0 and r.get("VGPRSpill", 0) == 0 and r.get("SGPRSpill", 0) == 0, (name, r)
+
+
+@pytest.mark.parametrize("kernel,min_occ", [("k_build_fused", 6), ("k_dedup", 6), ("k_chunk_place", 6), ("k_part_scatter", 4)])
+def test_lds_bound_kernels_keep_their_occupancy(resources, kernel, min_occ):
+    hits = {n: r for n, r in resources.items() if kernel + "I" in n}
+    assert hits, kernel
+    for name, r in hits.items():
+        assert r["Occupancy"] >= min_occ, (name, r)
