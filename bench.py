@@ -47,9 +47,62 @@ def gen_inputs(rank, n, nq, workload="w2"):
     return keys, vals, q
 
 
+def _cpu_shard_worker(path):
+    """one 'rank' of the sharded CPU baseline: private oracle table over its share of the sample (own process, like the
+    reference's MPI ranks: page faults of the doubling tables do not contend on one address space).  Prints one JSON line."""
+    from oracle import oracle_py as O
+    d = np.load(path)
+    t = O.OracleTable(O.KIND_RH, 128, 0.35, 0.8, O.HASH_MURMUR3_X86, 43)
+    t0 = time.time()
+    ti = t.timed_insert(d["k"], d["v"])
+    tf = t.timed_find(d["q"])[0]
+    print(json.dumps([ti, tf, t0, time.time()]), flush=True)
+
+
+def _cpu_sharded(keys, vals, q, P):
+    import shutil
+    import subprocess
+    import tempfile
+    from oracle import oracle_py as O
+    O.lib()                                    # compiled before the workers start
+    r = (O.hash_batch(O.HASH_MURMUR3_X86, 9876543, keys) % np.uint64(P)).astype(np.int32)
+    rq = (O.hash_batch(O.HASH_MURMUR3_X86, 9876543, q) % np.uint64(P)).astype(np.int32)
+    tmp = tempfile.mkdtemp(prefix="kh_cpu_")
+    procs = []
+    try:
+        for i in range(P):
+            path = os.path.join(tmp, "s%d.npz" % i)
+            np.savez(path, k=keys[r == i], v=vals[r == i], q=q[rq == i])
+        # plain child processes (fresh interpreters), started before this process touches the GPU
+        code = "import sys; sys.path.insert(0, %r); import bench; bench._cpu_shard_worker(sys.argv[1])" % ROOT
+        for i in range(P):
+            procs.append(subprocess.Popen([sys.executable, "-c", code, os.path.join(tmp, "s%d.npz" % i)],
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True))
+        res = []
+        for pr in procs:
+            o, _ = pr.communicate(timeout=300)
+            if pr.returncode != 0:
+                raise RuntimeError("cpu shard worker failed (rc %d)" % pr.returncode)
+            res.append(json.loads(o.strip().splitlines()[-1]))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        shutil.rmtree(tmp, ignore_errors=True)
+    wi, wf = max(a for a, _, _, _ in res), max(b for _, b, _, _ in res)
+    overlap = min(e for _, _, _, e in res) - max(s for _, _, s, _ in res)     # > 0: all ranks ran concurrently
+    return {"cores": P, "value": (len(keys) + len(q)) / (wi + wf), "inserts_per_s": len(keys) / wi, "finds_per_s": len(q) / wf,
+            "concurrent": bool(overlap > 0),
+            "sample": "the same sample split over %d private tables by murmur3(key, 9876543) %% %d, one process each "
+                      "(the reference's MPI model without the exchange)" % (P, P)}
+
+
 def cpu_baseline(keys, vals, q):
-    """the CPU oracle (own restatement of the reference RH table: kind 'port') timed on one host core, on a
-    bounded sample of the same stream"""
+    """the CPU oracle (own restatement of the reference RH table: kind 'port') timed on the host cores, on a bounded
+    sample of the same stream.  value: ONE thread (the reference is single-threaded per rank: the benchmark_hashtables
+    number).  'sharded': the reference's MPI model without the communication: P threads, thread r owns
+    the keys with murmur3(key, seed 9876543) % P == r in a private table; aggregate rate over the slowest thread."""
+    import threading
     from oracle import oracle_py as O
     n = min(len(keys), 20_000_000)
     nq = min(len(q), 2_000_000)
@@ -57,9 +110,17 @@ def cpu_baseline(keys, vals, q):
     ti = t.timed_insert(keys[:n], vals[:n])
     tf, hits = t.timed_find(q[:nq])
     assert hits == nq
-    return {"value": (n + nq) / (ti + tf), "unit": "kmer_ops/s", "cores": 1, "kind": "port",
-            "sample": "first %d inserts + %d finds of the same stream, oracle RH table (1 thread, g++ -O3)" % (n, nq),
-            "inserts_per_s": n / ti, "finds_per_s": nq / tf}
+    out = {"value": (n + nq) / (ti + tf), "unit": "kmer_ops/s", "cores": 1, "kind": "port",
+           "sample": "first %d inserts + %d finds of the same stream, oracle RH table (1 thread, g++ -O3)" % (n, nq),
+           "inserts_per_s": n / ti, "finds_per_s": nq / tf}
+    del t
+    try:
+        P = max(1, min(len(os.sched_getaffinity(0)), 64))
+        if P > 1:
+            out["sharded"] = _cpu_sharded(keys[:n], vals[:n], q[:nq], P)
+    except Exception as e:                    # the single-thread figure stands on its own
+        out["sharded"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -83,14 +144,17 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    import kmerhash_amd as kh
-    from kmerhash_amd import dist as khd
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or os.environ.get("KH_DIST_FORCE_COLLECTIVES", "0") == "1"   # rehearsal of the N>1 path on one GPU
+    keys, vals, q = gen_inputs(rank, args.keys, args.queries, args.workload)
+    # CPU baseline first (rank 0, N=1 only): its worker processes are started before this process touches the GPU
+    cpu = cpu_baseline(keys, vals, q) if (not args.no_cpu_baseline and not distributed) else None
+
+    import torch
+    import kmerhash_amd as kh
+    from kmerhash_amd import dist as khd
     if args.chunks <= 0:
         args.chunks = 4 if world > 1 else 1
     if distributed and "RANK" not in os.environ:
@@ -105,7 +169,6 @@ def main():
         local_rank = 0
     dev = torch.device("cuda", local_rank)
 
-    keys, vals, q = gen_inputs(rank, args.keys, args.queries, args.workload)
     n_distinct = len(np.unique(keys)) if args.workload == "w1" else args.keys
     dk = torch.from_numpy(keys.view(np.int64)).to(dev)
     dv = torch.from_numpy(vals.view(np.int32)).to(dev)
@@ -233,8 +296,8 @@ def main():
                          "whole_find_path_frac": find_rate / world * B_FIND_HIT / 1e9 / HBM_PEAK_GBS},
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
         }
-        if not args.no_cpu_baseline and not distributed:
-            out["cpu_baseline"] = cpu_baseline(keys, vals, q)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
