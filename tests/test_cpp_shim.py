@@ -47,3 +47,23 @@ def test_cpp_benchmark_driver_small():
         r = subprocess.run([BENCH_BIN, "-m", m, "-N", "200000", "-Q", "10", "-R", "10"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "count2" in r.stdout
+
+
+def test_cpp_benchmark_driver_flag_errors():
+    """flag surface of the reference driver (BenchmarkHashTables.cpp:1439-1486): what this path does not have is refused
+    with a message, before any GPU work (runs without a GPU)"""
+    _compile(BENCH_SRC, BENCH_BIN)
+    for argv, msg in ((["-A", "dna5"], "only dna"), (["-I", "bogus"], "unknown insert mode"),
+                      (["-m", "linearprobe", "-I", "sort"], "robinhood map only"), (["--no-such-flag"], "usage")):
+        r = subprocess.run([BENCH_BIN] + argv + ["-N", "10"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and msg in r.stderr, (argv, r.stderr)
+
+
+@pytest.mark.gpu
+def test_cpp_benchmark_driver_reference_flags():
+    _compile(BENCH_SRC, BENCH_BIN)
+    for extra in (["-I", "iter"], ["-I", "integrated", "-c"], ["-I", "shuffle", "-f", "--measured_op", "find", "--insert_prefetch", "8"]):
+        r = subprocess.run([BENCH_BIN, "-m", "robinhood", "-N", "100000", "-A", "dna"] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "SELF-CHECK FAILED" not in r.stdout and "count2" in r.stdout
+    assert "*find" in r.stdout
