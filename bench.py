@@ -47,15 +47,18 @@ def gen_inputs(rank, n, nq, workload="w2"):
     return keys, vals, q
 
 
-def _cpu_shard_worker(path):
+def _cpu_shard_worker(path, start_at=0.0):
     """one 'rank' of the sharded CPU baseline: private oracle table over its share of the sample (own process, like the
     reference's MPI ranks: page faults of the doubling tables do not contend on one address space).  Prints one JSON line."""
     from oracle import oracle_py as O
     d = np.load(path)
+    k, v, qq = d["k"], d["v"], d["q"]
     t = O.OracleTable(O.KIND_RH, 128, 0.35, 0.8, O.HASH_MURMUR3_X86, 43)
+    while time.time() < start_at:              # common start time: all ranks run concurrently
+        time.sleep(0.001)
     t0 = time.time()
-    ti = t.timed_insert(d["k"], d["v"])
-    tf = t.timed_find(d["q"])[0]
+    ti = t.timed_insert(k, v)
+    tf = t.timed_find(qq)[0]
     print(json.dumps([ti, tf, t0, time.time()]), flush=True)
 
 
@@ -74,9 +77,10 @@ def _cpu_sharded(keys, vals, q, P):
             path = os.path.join(tmp, "s%d.npz" % i)
             np.savez(path, k=keys[r == i], v=vals[r == i], q=q[rq == i])
         # plain child processes (fresh interpreters), started before this process touches the GPU
-        code = "import sys; sys.path.insert(0, %r); import bench; bench._cpu_shard_worker(sys.argv[1])" % ROOT
+        code = "import sys; sys.path.insert(0, %r); import bench; bench._cpu_shard_worker(sys.argv[1], float(sys.argv[2]))" % ROOT
+        start_at = time.time() + 4.0
         for i in range(P):
-            procs.append(subprocess.Popen([sys.executable, "-c", code, os.path.join(tmp, "s%d.npz" % i)],
+            procs.append(subprocess.Popen([sys.executable, "-c", code, os.path.join(tmp, "s%d.npz" % i), repr(start_at)],
                                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True))
         res = []
         for pr in procs:
@@ -93,8 +97,8 @@ def _cpu_sharded(keys, vals, q, P):
     overlap = min(e for _, _, _, e in res) - max(s for _, _, s, _ in res)     # > 0: all ranks ran concurrently
     return {"cores": P, "value": (len(keys) + len(q)) / (wi + wf), "inserts_per_s": len(keys) / wi, "finds_per_s": len(q) / wf,
             "concurrent": bool(overlap > 0),
-            "sample": "the same sample split over %d private tables by murmur3(key, 9876543) %% %d, one process each "
-                      "(the reference's MPI model without the exchange)" % (P, P)}
+            "sample": "first %d inserts + %d finds of the same stream split over %d private tables by murmur3(key, 9876543) %% %d, "
+                      "one process each, common start (the reference's MPI model without the exchange)" % (len(keys), len(q), P, P)}
 
 
 def cpu_baseline(keys, vals, q):
@@ -115,9 +119,10 @@ def cpu_baseline(keys, vals, q):
            "inserts_per_s": n / ti, "finds_per_s": nq / tf}
     del t
     try:
-        P = max(1, min(len(os.sched_getaffinity(0)), 64))
+        P = max(1, min(len(os.sched_getaffinity(0)), 16))       # the GPU box's CPU share for one GPU is 16 cores
         if P > 1:
-            out["sharded"] = _cpu_sharded(keys[:n], vals[:n], q[:nq], P)
+            ns, nqs = min(len(keys), 2 * n), min(len(q), 2 * nq)    # the ranks run in parallel: a larger sample fits the time budget
+            out["sharded"] = _cpu_sharded(keys[:ns], vals[:ns], q[:nqs], P)
     except Exception as e:                    # the single-thread figure stands on its own
         out["sharded"] = {"error": repr(e)}
     return out
@@ -263,11 +268,10 @@ def main():
         # prescribes); PMC counters cannot be read from inside the timed process, so this is the recorded figure
         traffic = None
         try:
-            import glob
-            pj = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
-            if pj and not distributed:
-                traffic = json.load(open(pj[-1])).get(dom, {}).get("hbm_bytes_per_launch")
-                traffic_src = os.path.basename(pj[-1])
+            tag = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()      # written by scripts/summarize_profiles.py
+            traffic_src = "%s_pmc_hbm_traffic.json" % tag
+            if not distributed:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", traffic_src))).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
         launches_per_step = launches / args.steps

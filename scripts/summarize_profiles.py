@@ -45,4 +45,5 @@ with open("profiles/%s_pmc_hbm_traffic.csv" % tag, "w") as f:
         f.write("%s,%d,%.1f,%.1f,%.0f,%.0f,%.0f\n" % (k, e.get("FETCH_SIZE_launches", 0), e.get("FETCH_SIZE_KB_per_launch_raw", 0),
                                                    e.get("WRITE_SIZE_KB_per_launch_raw", 0), e["read_bytes_per_launch"],
                                                    e["write_bytes_per_launch"], e["hbm_bytes_per_launch"]))
+open("profiles/LATEST", "w").write(tag + "\n")      # bench.py reads roofline.traffic from the summary this names
 print(open("profiles/%s_pmc_hbm_traffic.csv" % tag).read())
