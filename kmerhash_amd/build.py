@@ -30,7 +30,7 @@ def build_library(force=False, verbose=False):
     if not force and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-comment", "-Rpass-analysis=kernel-resource-usage", "-o", LIB, SRC]
+           "-Wno-unused-value", "-Wno-comment", "-Rpass-analysis=kernel-resource-usage", "-o", LIB, SRC] + os.environ.get("KH_EXTRA_FLAGS", "").split()
     if verbose:
         print(" ".join(cmd))
     p = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)

@@ -552,11 +552,9 @@ __device__ __forceinline__ uint32_t kh_dd_fold(const unsigned long long* lk, uns
       const unsigned long long key = lk[x];
       uint32_t slot = (uint32_t)kh_fmix64(key + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
       for (;;) {
-        uint32_t cur = set[slot];
-        if (cur == 0) {
-          cur = atomicCAS(&set[slot], 0u, x + 1u);
-          if (cur == 0) { rep_mask |= 1u << it; break; }
-        }
+        // one LDS round trip per probe: the CAS itself tells whether the entry was free (most are: load <= 0.37)
+        const uint32_t cur = atomicCAS(&set[slot], 0u, x + 1u);
+        if (cur == 0) { rep_mask |= 1u << it; break; }
         const uint32_t rep = cur - 1u;
         if (lk[rep] == key) {
           const unsigned long long iv = liv[x];
