@@ -22,6 +22,7 @@
 #define KH_HS 4096u              // LDS de-dup set entries per workgroup (16 B each)
 #define KH_CHUNK_THREADS 512
 #define KH_PART_THREADS 512
+#define KH_PART_MAXPER 4            // digits per lane in the scatter's scan: nb <= 2048 bins
 #define KH_PART_ITEMS 8
 #define KH_PART_TILE (KH_PART_THREADS * KH_PART_ITEMS)   // 4096 records per partition tile
 #define KH_NONE 0xFFFFFFFFFFFFFFFFull
@@ -375,13 +376,18 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
   __syncthreads();
   uint32_t run = incl - mine;
   for (uint32_t w = 0; w < wid; ++w) run += wtot[w];
-  for (uint32_t k = 0; k < per; ++k) {
-    uint32_t b = tid * per + k;
-    if (b < nb) {
-      uint32_t c = hist[b];
+  // the reservations are device-scope returning atomics (~2 us each way): issue them, stage the tile in LDS meanwhile
+  // (staging needs the in-tile offsets only), collect the results afterwards
+  unsigned long long gres[KH_PART_MAXPER];
+#pragma unroll
+  for (uint32_t k = 0; k < KH_PART_MAXPER; ++k) {
+    gres[k] = 0;
+    const uint32_t b = tid * per + k;
+    if (k < per && b < nb) {
+      const uint32_t c = hist[b];
       loff[b] = run;
       run += c;
-      if (c) gbase[b] = atomicAdd(&P.cursor[(uint64_t)d.seg * nb + b], (unsigned long long)c);
+      if (c) gres[k] = atomicAdd(&P.cursor[(uint64_t)d.seg * nb + b], (unsigned long long)c);
     }
   }
   __syncthreads();
@@ -392,6 +398,11 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
       uint32_t s = loff[dg[j]] + rk[j];
       lrec[s] = make_ulonglong2(key[j], iv[j]); ld[s] = (uint16_t)dg[j];
     }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < KH_PART_MAXPER; ++k) {
+    const uint32_t b = tid * per + k;
+    if (k < per && b < nb) gbase[b] = gres[k];
   }
   __syncthreads();
   for (uint32_t s = tid; s < d.len; s += KH_PART_THREADS) {
