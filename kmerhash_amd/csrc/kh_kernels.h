@@ -23,8 +23,9 @@
 #define KH_CHUNK_THREADS 512
 #define KH_PART_THREADS 512
 #define KH_PART_MAXPER 4            // digits per lane in the scatter's scan: nb <= 2048 bins
-#define KH_PART_ITEMS 8
-#define KH_PART_TILE (KH_PART_THREADS * KH_PART_ITEMS)   // 4096 records per partition tile
+#define KH_PART_ITEMS 16
+#define KH_PART_TILE (KH_PART_THREADS * KH_PART_ITEMS)   // 8192 records per partition tile: ONE reservation per (tile, digit)
+#define KH_PART_STAGE 4096       // records staged in LDS at a time: the tile is streamed out in TILE/STAGE rounds
 #define KH_NONE 0xFFFFFFFFFFFFFFFFull
 #define KH_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
@@ -331,8 +332,8 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_hist(KhPartParams P) {
 template <int HASH>
 __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P) {
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
-  __shared__ ulonglong2 lrec[KH_PART_TILE];
-  __shared__ uint16_t ld[KH_PART_TILE];
+  __shared__ ulonglong2 lrec[KH_PART_STAGE];
+  __shared__ uint16_t ld[KH_PART_STAGE];
   __shared__ uint32_t wtot[KH_PART_THREADS / 64];
   const uint32_t nb = P.nb;
   uint32_t* hist = kh_dyn_smem;                 // [nb] counts, then reused as running fill
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
   __syncthreads();
   uint64_t key[KH_PART_ITEMS];
   unsigned long long iv[KH_PART_ITEMS];
-  uint32_t dg[KH_PART_ITEMS], rk[KH_PART_ITEMS];
+  uint32_t dr[KH_PART_ITEMS];                   // digit << 16 | rank inside the digit (rank < 8192)
 #pragma unroll
   for (int j = 0; j < KH_PART_ITEMS; ++j) {
     uint32_t i = tid + j * KH_PART_THREADS;
@@ -357,9 +358,15 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
         iv[j] = ((unsigned long long)(P.idx_base + d.beg + i) << 32) |
                 (P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : P.vconst);
       }
-      uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
-      dg[j] = (q >> P.shift) & (nb - 1);
-      rk[j] = atomicAdd(&hist[dg[j]], 1u);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < KH_PART_ITEMS; ++j) {
+    uint32_t i = tid + j * KH_PART_THREADS;
+    if (i < d.len) {
+      const uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
+      const uint32_t dg = (q >> P.shift) & (nb - 1);
+      dr[j] = (dg << 16) | atomicAdd(&hist[dg], 1u);
     }
   }
   __syncthreads();
@@ -376,8 +383,8 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
   __syncthreads();
   uint32_t run = incl - mine;
   for (uint32_t w = 0; w < wid; ++w) run += wtot[w];
-  // the reservations are device-scope returning atomics (~2 us each way): issue them, stage the tile in LDS meanwhile
-  // (staging needs the in-tile offsets only), collect the results afterwards
+  // the reservations are device-scope returning atomics (6 M of them per launch at 4096-record tiles cost 0.16 of the
+  // 0.83 ms: hence 8192-record tiles); issue them, stage the first round in LDS meanwhile, collect the results afterwards
   unsigned long long gres[KH_PART_MAXPER];
 #pragma unroll
   for (uint32_t k = 0; k < KH_PART_MAXPER; ++k) {
@@ -391,24 +398,31 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
     }
   }
   __syncthreads();
+  for (uint32_t r0 = 0; r0 < d.len; r0 += KH_PART_STAGE) {
+    if (r0) __syncthreads();                    // the previous round has been streamed out
 #pragma unroll
-  for (int j = 0; j < KH_PART_ITEMS; ++j) {
-    uint32_t i = tid + j * KH_PART_THREADS;
-    if (i < d.len) {
-      uint32_t s = loff[dg[j]] + rk[j];
-      lrec[s] = make_ulonglong2(key[j], iv[j]); ld[s] = (uint16_t)dg[j];
+    for (int j = 0; j < KH_PART_ITEMS; ++j) {
+      uint32_t i = tid + j * KH_PART_THREADS;
+      if (i < d.len) {
+        const uint32_t dg = dr[j] >> 16;
+        const uint32_t s = loff[dg] + (dr[j] & 0xFFFFu) - r0;     // position in the tile's digit order, relative to this round
+        if (s < KH_PART_STAGE) { lrec[s] = make_ulonglong2(key[j], iv[j]); ld[s] = (uint16_t)dg; }
+      }
     }
-  }
+    if (r0 == 0) {
 #pragma unroll
-  for (uint32_t k = 0; k < KH_PART_MAXPER; ++k) {
-    const uint32_t b = tid * per + k;
-    if (k < per && b < nb) gbase[b] = gres[k];
-  }
-  __syncthreads();
-  for (uint32_t s = tid; s < d.len; s += KH_PART_THREADS) {
-    uint32_t dd = ld[s];
-    uint64_t pos = gbase[dd] + (s - loff[dd]);
-    P.orec[pos] = lrec[s];
+      for (uint32_t k = 0; k < KH_PART_MAXPER; ++k) {
+        const uint32_t b = tid * per + k;
+        if (k < per && b < nb) gbase[b] = gres[k];
+      }
+    }
+    __syncthreads();
+    const uint32_t rl = d.len - r0 < KH_PART_STAGE ? d.len - r0 : KH_PART_STAGE;
+    for (uint32_t s = tid; s < rl; s += KH_PART_THREADS) {
+      const uint32_t dd = ld[s];
+      const uint64_t pos = gbase[dd] + (r0 + s - loff[dd]);
+      P.orec[pos] = lrec[s];
+    }
   }
 }
 
