@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="w2", choices=["w2", "w1"],
                     help="w2 = configs[1] (default, the metric's workload); w1 = benchmark_hashtables shape (x5.5 multiplicity), informational")
+    ap.add_argument("--hash", default="murmur3avx64", choices=["murmur3avx64", "murmur", "farm", "identity"],
+                    help="storage hash (default = the metric's: murmur3avx64; the others are informational)")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N>1: pieces of the pipelined exchange/insert (permute, xGMI transfer and radix partition of successive pieces "
                          "overlap); 1 = exchange, then one bulk insert; 0 = auto (4 when N>1: the exchange is link-bound at every N)")
@@ -190,11 +192,11 @@ def main():
 
     def one_step(timed):
         if distributed:
-            be = khd.GpuBackend(local_rank, "rh", 128, 0.35, 0.8, "murmur3avx64", 43)
+            be = khd.GpuBackend(local_rank, "rh", 128, 0.35, 0.8, args.hash, 43)
             t = khd.ShardedTable(be)
             table = be.table
         else:
-            table = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash="murmur3avx64", seed=43, device=local_rank)
+            table = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=args.hash, seed=43, device=local_rank)
             t = None
         if timed:
             table.profile_enable(True)
@@ -289,7 +291,7 @@ def main():
                                    % (args.keys, state[3], state[2] / state[3], args.queries,
                                       "; keys sharded by murmur3(seed 9876543) over RCCL all_to_all" if distributed else ""),
                        "keys_per_gpu": args.keys, "queries_per_gpu": args.queries, "table": "hashmap_robinhood_doubling",
-                       "hash": "murmur3avx64", "max_load_factor": 0.8, "min_load_factor": 0.35},
+                       "hash": args.hash, "max_load_factor": 0.8, "min_load_factor": 0.35},
             "inserts_per_s": ins_rate, "finds_per_s": find_rate,
             "insert_ms": float(np.mean(ins_ms)), "find_ms": float(np.mean(find_ms)),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <random>
 #include <unordered_map>
+#include <list>
 #include <vector>
 
 #include "kmerhash/hashmap_robinhood.hpp"
@@ -75,6 +76,19 @@ void differential(const char* name, size_t n, bool is_rh) {
   auto found = map.find(qk.begin(), qk.end());
   CHECK(found.size() == q);
   for (size_t i = 0; i < q; ++i) { CHECK(found[i].first == qk[i]); CHECK(found[i].second == gold[kmerhash_amd::detail::key_bits(qk[i])]); }
+  // the same queries through raw pointers, const_iterators (borrowed as they lie) and a non-contiguous container (gathered)
+  {
+    const Key* p0 = qk.data();
+    auto f2 = map.find(p0, p0 + qk.size());
+    auto c2 = map.count(qk.cbegin(), qk.cend());
+    std::list<Key> lk(qk.begin(), qk.end());
+    auto f3 = map.find(lk.begin(), lk.end());
+    auto c4 = map.count(lk.begin(), lk.end());
+    CHECK(f2.size() == found.size() && f3.size() == found.size() && c2 == counts && c4 == counts);
+    for (size_t i = 0; i < found.size(); ++i) { CHECK(f2[i] == found[i]); CHECK(f3[i] == found[i]); }
+    std::vector<Key> none;
+    CHECK(map.find(none.begin(), none.end()).empty() && map.count(none.data(), none.data()).empty());
+  }
   CHECK(map.count(qk[0]) == 1 && map.count(qk.back()) == 0);
   CHECK(map.find(qk[0]) != map.end() && map.find(qk[0])->second == gold[kmerhash_amd::detail::key_bits(qk[0])]);
   CHECK(map.find(qk.back()) == map.end());
