@@ -164,35 +164,59 @@ __global__ void k_flag_tile_sums(const uint8_t* __restrict__ flags, uint64_t n, 
 }
 
 // single-workgroup exclusive scan of u32 counts into u64 offsets (out has n+1 entries; out[n] = total).
-// 1024 lanes x 16 consecutive items per sweep.
-#define KH_SCAN_ITEMS 16
-__global__ void k_scan_u32_to_u64(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
-  __shared__ uint64_t wtot[16];
+// A sweep covers 16 chunks of 2048 counts: lane t owns counts [4t, 4t+4) of every chunk (one 16-byte load each, all 16 in
+// flight at once), the 16 chunk scans run in registers with ONE barrier between them and the write-out.  (The earlier
+// version swept 16384 counts at a time with three barriers and a dependent load per sweep: 77 us for the 65537 counts of
+// a 10^8-key partition.)
+#define KH_SCAN_THREADS 512
+#define KH_SCAN_CHUNKS 16
+#define KH_SCAN_CHUNK (KH_SCAN_THREADS * 4)
+__global__ __launch_bounds__(KH_SCAN_THREADS) void k_scan_u32_to_u64(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ out) {
+  __shared__ uint64_t wsum[KH_SCAN_CHUNKS][KH_SCAN_THREADS / 64];
   __shared__ uint64_t carry_s;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (uint64_t base = 0; base < n; base += 1024 * KH_SCAN_ITEMS) {
-    const uint64_t i0 = base + (uint64_t)tid * KH_SCAN_ITEMS;
-    uint32_t v[KH_SCAN_ITEMS];
-    uint64_t sum = 0;
+  for (uint64_t base = 0; base < n; base += (uint64_t)KH_SCAN_CHUNKS * KH_SCAN_CHUNK) {
+    uint32_t v[KH_SCAN_CHUNKS][4];
 #pragma unroll
-    for (int j = 0; j < KH_SCAN_ITEMS; ++j) { v[j] = (i0 + j < n) ? in[i0 + j] : 0u; sum += v[j]; }
-    uint64_t incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-      uint64_t o = __shfl_up(incl, off, 64);
-      if (lane >= (uint32_t)off) incl += o;
+    for (int c = 0; c < KH_SCAN_CHUNKS; ++c) {
+      const uint64_t i0 = base + (uint64_t)c * KH_SCAN_CHUNK + 4 * tid;
+      if (aligned && i0 + 4 <= n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(in + i0);
+        v[c][0] = q.x; v[c][1] = q.y; v[c][2] = q.z; v[c][3] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[c][j] = (i0 + j < n) ? in[i0 + j] : 0u;
+      }
     }
-    if (lane == 63) wtot[wid] = incl;
-    __syncthreads();
-    uint64_t wpre = 0;
-    for (uint32_t w = 0; w < wid; ++w) wpre += wtot[w];
-    const uint64_t carry = carry_s;
-    uint64_t run = carry + wpre + incl - sum;
+    uint64_t incl[KH_SCAN_CHUNKS];
 #pragma unroll
-    for (int j = 0; j < KH_SCAN_ITEMS; ++j) { if (i0 + j < n) out[i0 + j] = run; run += v[j]; }
+    for (int c = 0; c < KH_SCAN_CHUNKS; ++c) {
+      uint64_t x = (uint64_t)v[c][0] + v[c][1] + v[c][2] + v[c][3];
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t o = __shfl_up(x, off, 64);
+        if (lane >= (uint32_t)off) x += o;
+      }
+      incl[c] = x;
+      if (lane == 63) wsum[c][wid] = x;
+    }
     __syncthreads();
-    if (tid == 1023) carry_s = run;
+    uint64_t running = carry_s;
+#pragma unroll
+    for (int c = 0; c < KH_SCAN_CHUNKS; ++c) {
+      uint64_t wpre = 0, tot = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < KH_SCAN_THREADS / 64; ++w) { const uint64_t x = wsum[c][w]; if (w < wid) wpre += x; tot += x; }
+      uint64_t ex = running + wpre + incl[c] - ((uint64_t)v[c][0] + v[c][1] + v[c][2] + v[c][3]);
+      const uint64_t i0 = base + (uint64_t)c * KH_SCAN_CHUNK + 4 * tid;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { if (i0 + j < n) out[i0 + j] = ex; ex += v[c][j]; }
+      running += tot;
+    }
+    __syncthreads();
+    if (tid == 0) carry_s = running;
     __syncthreads();
   }
   if (tid == 0) out[n] = carry_s;

@@ -405,7 +405,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
                      hipLaunchKernelGGL((k_part_hist_full<HASH>), dim3(grid), dim3(KH_FULLHIST_THREADS), smem, t->stream,
                                         kbase, kstride, n, t->seed, PB, counts2)); }
     { Launch L(t, "k_scan");
-      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts2, (uint64_t)nparts, off2); }
+      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, counts2, (uint64_t)nparts, off2); }
     hipLaunchKernelGGL(k_seg_offsets, dim3((nb1 + 256) / 256), dim3(256), 0, t->stream, off2, nb1, nb2, off1, cur1);
   } else {
     HIPCHK(hipMemsetAsync(counts1, 0, sizeof(uint32_t) * nb1, t->stream));
@@ -413,7 +413,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     { Launch L(t, "k_part_hist");
       KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(hist_grid), dim3(KH_PART_THREADS), nb1 * 4, t->stream, P)); }
     { Launch L(t, "k_scan");
-      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts1, (uint64_t)nb1, off1); }
+      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, counts1, (uint64_t)nb1, off1); }
     HIPCHK(hipMemcpyAsync(cur1, off1, sizeof(uint64_t) * nb1, hipMemcpyDeviceToDevice, t->stream));
   }
   { Launch L(t, "k_part_scatter");
@@ -436,7 +436,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     { Launch L(t, "k_part_hist");
       KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); }
     { Launch L(t, "k_scan");
-      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, counts2, (uint64_t)nparts, off2); }
+      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, counts2, (uint64_t)nparts, off2); }
   }
   HIPCHK(hipMemcpyAsync(cur2, off2, sizeof(uint64_t) * nparts, hipMemcpyDeviceToDevice, t->stream));
   { Launch L(t, "k_part_scatter");
@@ -592,7 +592,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   { Launch L(t, "k_dedup");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
   { Launch L(t, "k_scan");
-    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, cnt_new, (uint64_t)R.nparts, noff); }
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, cnt_new, (uint64_t)R.nparts, noff); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(t->hpin, noff + R.nparts, 8, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipMemcpyAsync(t->hpin + 1, scal, 8, hipMemcpyDeviceToHost, t->stream));
@@ -710,7 +710,7 @@ kh_status compact(kh_table* t, const uint8_t* flags, const uint64_t* q, const ui
   { Launch L(t, "k_flag_tile_sums");
     hipLaunchKernelGGL(k_flag_tile_sums, dim3((uint32_t)ntl), dim3(256), 0, t->stream, flags, n, sums); }
   { Launch L(t, "k_scan");
-    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, t->stream, sums, ntl, offs); }
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, sums, ntl, offs); }
   if (out_keys || out_pairs) {
     Launch L(t, "k_compact_hits");
     hipLaunchKernelGGL(k_compact_hits, dim3((uint32_t)ntl), dim3(256), 0, t->stream, flags, q, vals, n, offs, out_keys, out_vals, out_pairs);
@@ -1151,7 +1151,7 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64
   HIPCHK(pool_alloc(device, m * 4, reinterpret_cast<void**>(&tc)));
   if (pool_alloc(device, (m + 1) * 8, reinterpret_cast<void**>(&toff)) != hipSuccess) { pool_free(device, tc); return KH_ERR_NOMEM; }
   KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_count<HASH>), dim3(ntiles), dim3(KH_SHARD_THREADS), 0, stream, keys, n, seed, p, pmask, tc, ntiles));
-  hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, stream, tc, m, toff);
+  hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, stream, tc, m, toff);
   if (!out_keys) {
     // count only: the caller sizes the exchange before it permutes (pipelined multi-GPU insert)
   } else if (p <= 8) {
@@ -1204,7 +1204,7 @@ kh_status kh_kmers_from_sequence(const void* seq, uint64_t n, uint32_t k, int ca
     if (canonical) hipLaunchKernelGGL((k_kmers<true>), dim3(grid), dim3(256), 0, stream, dseq, n, k, km, fl);
     else hipLaunchKernelGGL((k_kmers<false>), dim3(grid), dim3(256), 0, stream, dseq, n, k, km, fl);
     hipLaunchKernelGGL(k_flag_tile_sums, dim3((uint32_t)ntl), dim3(256), 0, stream, fl, n, sums);
-    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(1024), 0, stream, sums, ntl, offs);
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, stream, sums, ntl, offs);
     hipLaunchKernelGGL(k_compact_hits, dim3((uint32_t)ntl), dim3(256), 0, stream, fl, km, (const uint32_t*)nullptr, n, offs, dout, (uint32_t*)nullptr, (uint8_t*)nullptr);
     e = hipGetLastError();
   }
