@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   __shared__ unsigned long long lk[KH_DD_M];
   __shared__ unsigned long long liv[KH_DD_M];
   __shared__ uint32_t set[KH_HS];               // de-dup index set, later cnt/fill = set[0..L) and start = set[L..2L)
-  // the chunk image is kept as 16-bit indices into the staged records (0xFFFF = empty slot): 4.3 KB instead of the
+  // the chunk image is kept as 16-bit entries (11-bit index into the staged records | 5-bit distance code; 0xFFFF = empty slot): 4.3 KB instead of the
   // 28 KB of a (key, value, info) image, which keeps the kernel at 53.7 KB of LDS = 3 workgroups per CU
   __shared__ __align__(8) uint16_t simg[KH_L + KH_FSPILL];
   __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
@@ -1172,7 +1172,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   const uint64_t Sc = (uint64_t)c * KH_L;
   const unsigned long long VALID = 1ull << 63;
   const bool aborted = s_abort != 0;
-  if (m > KH_DD_M || aborted) {      // does not fit the staging area / speculation given up: general path
+  // (record indices travel as 11-bit fields next to a 5-bit distance code, 0xFFFF = empty slot: index 2047 stays unused)
+  if (m >= KH_DD_M || aborted) {     // does not fit the staging area / speculation given up: general path
     if (tid == 0) {
       // (an aborted launch was flagged once by the workgroup that gave up: 65 K atomics on one word would cost 2 ms)
       if (!aborted) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
@@ -1296,7 +1297,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       const uint32_t prel = start[b] + r;
       uint32_t dist = prel - b;
       if (KIND == KHK_RH && dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
-      if (prel < KH_L + KH_FSPILL) simg[prel] = (uint16_t)x;
+      if (prel < KH_L + KH_FSPILL) simg[prel] = (uint16_t)(x | ((dist < 31u ? dist : 31u) << 11));   // record index | distance code
       else {
         const uint64_t pos = (Sc + prel) & mask_n;
         P.New.keys[pos] = lk[x]; P.New.vals[pos] = (uint32_t)liv[x];
@@ -1311,17 +1312,21 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   const uint32_t hi = pend < (long long)(KH_L + KH_FSPILL) ? (uint32_t)pend : (KH_L + KH_FSPILL);
   for (uint32_t s0 = lo + tid; s0 < hi; s0 += KH_CHUNK_THREADS) {
     const uint64_t pos = (Sc + s0) & mask_n;
-    const uint32_t x = simg[s0];
-    if (x == 0xFFFFu) {
+    const uint32_t e = simg[s0];
+    if (e == 0xFFFFu) {
       P.New.keys[pos] = 0; P.New.vals[pos] = 0;
       P.New.info[pos] = KIND == KHK_RH ? (uint8_t)0x00 : (uint8_t)0x40;
     } else {
+      const uint32_t x = e & 0x7FFu;
       const uint64_t key = lk[x];
       P.New.keys[pos] = key;
       P.New.vals[pos] = (uint32_t)liv[x];
-      if (KIND == KHK_RH) {     // distance = slot - home; the home is re-derived from the key (cheaper than 2 KB of LDS)
-        uint32_t dist = s0 - (uint32_t)((kh_hash64<HASH>(key, P.seed) & mask_n) - Sc);
-        if (dist > 127u) dist = 127u;
+      if (KIND == KHK_RH) {     // distance = slot - home: the 5-bit code next to the record index; the rare long ones are re-derived from the key
+        uint32_t dist = e >> 11;
+        if (dist == 31u) {
+          dist = s0 - (uint32_t)((kh_hash64<HASH>(key, P.seed) & mask_n) - Sc);
+          if (dist > 127u) dist = 127u;
+        }
         P.New.info[pos] = (uint8_t)(0x80u | dist);
       } else P.New.info[pos] = 0x00;
     }
@@ -1333,20 +1338,22 @@ __global__ void k_fused_tail_carry(const unsigned long long* __restrict__ pub, u
   if (threadIdx.x == 0 && blockIdx.x == 0) xcarry0[0] = (long long)((pub[nch - 1] >> 32) & 0x7FFFFFFFull);
 }
 
-// totals of a fused build: sum of the per-chunk counts (low word of the published granules) and max of maxidx
-__global__ void k_fused_totals(const unsigned long long* __restrict__ pub, const uint32_t* __restrict__ maxidx, uint32_t nch,
-                               unsigned long long* __restrict__ totals) {
+// totals of a fused build: sum of the per-chunk counts (low word of the published granules) and max of maxidx.
+// totals[0..1] are zero at launch; every workgroup reduces its slice and adds it with ONE atomic per value.
+__global__ __launch_bounds__(1024) void k_fused_totals(const unsigned long long* __restrict__ pub, const uint32_t* __restrict__ maxidx, uint32_t nch,
+                                                       unsigned long long* __restrict__ totals) {
   __shared__ unsigned long long ws[16];
   __shared__ uint32_t wm[16];
   unsigned long long sum = 0; uint32_t mx = 0;
-  for (uint32_t c = threadIdx.x; c < nch; c += 1024) { sum += pub[c] & 0xFFFFFFFFull; const uint32_t v = maxidx[c]; mx = v > mx ? v : mx; }
+  for (uint32_t c = blockIdx.x * 1024 + threadIdx.x; c < nch; c += gridDim.x * 1024) { sum += pub[c] & 0xFFFFFFFFull; const uint32_t v = maxidx[c]; mx = v > mx ? v : mx; }
   for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off, 64); const uint32_t o = __shfl_down(mx, off, 64); mx = o > mx ? o : mx; }
   if ((threadIdx.x & 63) == 0) { ws[threadIdx.x >> 6] = sum; wm[threadIdx.x >> 6] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long t = 0; uint32_t m = 0;
     for (int w = 0; w < 16; ++w) { t += ws[w]; m = wm[w] > m ? wm[w] : m; }
-    totals[0] = t; totals[1] = m;
+    if (t) atomicAdd(&totals[0], t);
+    if (m) atomicMax(&totals[1], (unsigned long long)m);
   }
 }
 

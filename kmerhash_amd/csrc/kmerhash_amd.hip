@@ -522,7 +522,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     { Launch L(t, "k_build_fused");
       KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     { Launch L(t, "k_fused_totals");
-      hipLaunchKernelGGL(k_fused_totals, dim3(1), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
+      hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
     { // chunk 0: placed now that the last chunk's run-over is known (one workgroup of the general placement kernel)
       Launch L(t, "k_fused_tail");
       hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);

@@ -463,6 +463,31 @@ def test_extreme_multiplicity_and_dense_chunks(oracle, kname, cls, kind):
 
 
 @pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_fused_build_long_probe_distances(oracle, kname, cls, kind):
+    """bulk build with home buckets shared by 20..100 keys (identity hash, keys equal modulo the capacity): probe distances
+    far beyond the 5-bit code the fused kernel keeps next to each staged record (>= 31 are re-derived from the key)"""
+    cap = 1 << 16
+    base = np.arange(30_000, dtype=np.uint64) * np.uint64(2)              # spread: every second bucket
+    piles = []
+    for b, cnt in ((100, 100), (2047, 60), (2048, 45), (40_000, 33), (65_535, 20), (12_345, 31), (12_400, 32)):
+        piles.append(np.uint64(b) + (np.arange(1, cnt + 1, dtype=np.uint64) << np.uint64(32)))
+    keys = np.concatenate([base] + piles)
+    keys = keys[np.random.default_rng(3).permutation(len(keys))]
+    vals = np.arange(len(keys), dtype=np.uint32)
+    g = cls(cap, 0.35, 0.8, hash="identity")
+    o = oracle.OracleTable(kind, cap, 0.35, 0.8, 0, 43)
+    n_new = o.insert(keys, vals)
+    assert not o.probe_overflow()
+    assert g.insert(dev(keys), dev(vals)) == n_new == len(keys)
+    assert g.capacity() == o.capacity() == cap
+    check_state(g, o, kind)
+    if kind == 0:
+        assert int(np.flatnonzero(g.displacement_histogram())[-1]) >= 100
+    check_queries(g, o, keys[:2000])
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
 @pytest.mark.parametrize("cap0", [0, 1, 2, 3, 5, 64, 1000, 5000])
 def test_tiny_and_odd_initial_capacities(oracle, kname, cls, kind, cap0):
     """ctor capacity is rounded up to a power of two (next_power_of_2; 0 and 1 give 1); tables of 1, 2, 4 ... buckets
