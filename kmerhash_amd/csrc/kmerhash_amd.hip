@@ -81,6 +81,27 @@ void pool_free(int dev, void* p) {
   P.free_.insert(std::make_pair(it->second, p));
   P.cached += it->second;
 }
+// pinned host scratch blocks (512 B, one per table) and profiling events are recycled too: hipHostFree synchronises the
+// device (0.2 ms per table destroyed, 4% of a benchmark step)
+struct HostPool { std::mutex m; std::vector<uint64_t*> pinned; std::vector<hipEvent_t> events[16]; };   // events: per device
+HostPool g_host;
+uint64_t* pinned_get() {
+  { std::lock_guard<std::mutex> g(g_host.m);
+    if (!g_host.pinned.empty()) { uint64_t* p = g_host.pinned.back(); g_host.pinned.pop_back(); return p; } }
+  uint64_t* p = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void**>(&p), 64 * sizeof(uint64_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void pinned_put(uint64_t* p) { if (p) { std::lock_guard<std::mutex> g(g_host.m); g_host.pinned.push_back(p); } }
+hipEvent_t event_get(int dev) {      // the caller has made `dev` current
+  { std::lock_guard<std::mutex> g(g_host.m);
+    auto& v = g_host.events[dev & 15];
+    if (!v.empty()) { hipEvent_t e = v.back(); v.pop_back(); return e; } }
+  hipEvent_t e = nullptr;
+  hipEventCreate(&e);
+  return e;
+}
+void event_put(int dev, hipEvent_t e) { if (e) { std::lock_guard<std::mutex> g(g_host.m); g_host.events[dev & 15].push_back(e); } }
 }  // namespace
 
 namespace {
@@ -225,7 +246,7 @@ void retire_slots(kh_table* t, KhSlots& s) {   // keep one spare buffer for ping
 struct Launch {
   kh_table* t; const char* name; hipEvent_t a, b; bool on;
   Launch(kh_table* t_, const char* n) : t(t_), name(n), a(nullptr), b(nullptr), on(t_ && t_->prof) {
-    if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, t->stream); }
+    if (on) { a = event_get(t->device); b = event_get(t->device); hipEventRecord(a, t->stream); }
   }
   ~Launch() {
     if (on) { hipEventRecord(b, t->stream); ProfRec r; r.name = name; r.a = a; r.b = b; t->recs.push_back(r); }
@@ -237,7 +258,7 @@ void prof_collect(kh_table* t) {
   for (auto& r : t->recs) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, r.a, r.b);
-    hipEventDestroy(r.a); hipEventDestroy(r.b);
+    event_put(t->device, r.a); event_put(t->device, r.b);
     bool found = false;
     for (auto& a : t->prof_acc) if (a.first == r.name) { a.second.first += ms; a.second.second += 1; found = true; break; }
     if (!found) t->prof_acc.push_back(std::make_pair(std::string(r.name), std::make_pair(double(ms), uint64_t(1))));
@@ -843,8 +864,9 @@ kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t v
   memset(&t->ins, 0, sizeof(t->ins));
   const uint64_t cap = next_pow2(capacity);
   if (alloc_slots(t, cap, t->cur) != KH_OK) { delete t; return KH_ERR_NOMEM; }
-  if (hipHostMalloc(reinterpret_cast<void**>(&t->hpin), 64 * sizeof(uint64_t)) != hipSuccess) { free_slots(t, t->cur); delete t; return KH_ERR_NOMEM; }
-  if (hipMemset(t->cur.info, empty_byte(t->kind), cap + 256) != hipSuccess) { free_slots(t, t->cur); hipHostFree(t->hpin); delete t; return KH_ERR_HIP; }
+  t->hpin = pinned_get();
+  if (!t->hpin) { free_slots(t, t->cur); delete t; return KH_ERR_NOMEM; }
+  if (hipMemset(t->cur.info, empty_byte(t->kind), cap + 256) != hipSuccess) { free_slots(t, t->cur); pinned_put(t->hpin); delete t; return KH_ERR_HIP; }
   t->min_load = threshold(cap, min_lf);
   t->max_load = threshold(cap, max_lf);
   *out = t;
@@ -855,10 +877,10 @@ kh_status kh_destroy(kh_table* t) {
   if (!t) return KH_OK;
   hipSetDevice(t->device);
   hipStreamSynchronize(t->stream);
-  for (auto& r : t->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (auto& r : t->recs) { event_put(t->device, r.a); event_put(t->device, r.b); }
   free_slots(t, t->cur); free_slots(t, t->spare);
   for (auto& b : t->blocks) pool_free(t->device, b.p);
-  if (t->hpin) hipHostFree(t->hpin);
+  pinned_put(t->hpin);
   delete t;
   return KH_OK;
 }
