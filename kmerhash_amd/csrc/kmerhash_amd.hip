@@ -713,7 +713,9 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
   }
   uint64_t total_new = 0;
   kh_status st = insert_device(t, kb, kstride, vb, vstride, n, mode, &total_new);
-  if (st == KH_OK) st = do_reserve(t, t->lsize);   // trailing reserve(lsize) of insert(Iter,Iter) (:672 / :546): a no-op unless size > max_load
+  // trailing reserve(lsize) of insert(Iter,Iter) (:672 / :546): a no-op unless size > max_load (after set_max_load_factor).
+  // kh_update stands for a sequence of update(k,v) calls (:1274), which has no such tail
+  if (st == KH_OK && mode != INS_UPDATE) st = do_reserve(t, t->lsize);
   if (st == KH_OK) HIPCHK(hipStreamSynchronize(t->stream));
   arena_consolidate(t);
   if (n_inserted) *n_inserted = total_new;

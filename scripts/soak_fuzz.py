@@ -1,0 +1,77 @@
+"""soak: long differential fuzz of both tables against the CPU oracle (TEST INFRASTRUCTURE use of oracle/, like tests/).
+usage: python scripts/soak_fuzz.py [seconds] [first_seed]   -- prints the failing (seed, step, op) if anything differs"""
+import sys, time
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import numpy as np, torch
+import kmerhash_amd as kh
+from kmerhash_amd import workloads as W
+from oracle import oracle_py as O
+from test_gpu_parity import check_state, check_queries, dev
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+only_one = len(sys.argv) > 3
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+KINDS = [(kh.hashmap_robinhood_doubling, 0), (kh.hashmap_linearprobe_doubling, 1)]
+HASHES = [("murmur3avx64", 1), ("murmur", 2), ("farm", 3)]
+t_end = time.time() + budget
+runs = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed)
+    cls, kind = KINDS[int(rng.integers(0, 2))]
+    hname, hid = HASHES[int(rng.integers(0, 3))]
+    mn = float(rng.choice([0.1, 0.35, 0.4])); mx = float(rng.choice([0.5, 0.7, 0.8, 0.9, 0.95]))
+    cap0 = int(rng.choice([1, 128, 4096, 1 << 15]))
+    usize = int(rng.choice([3_000, 60_000, 600_000]))
+    g = cls(cap0, mn, mx, hash=hname, seed=43)
+    o = O.OracleTable(kind, cap0, mn, mx, hid, 43)
+    universe = W.splitmix64(np.arange(usize, dtype=np.uint64) + np.uint64(seed << 24))
+    step = -1; op = -1
+    try:
+        for step in range(40):
+            op = int(rng.integers(0, 13))
+            m = int(rng.choice([0, 1, 3, 50, 2000, 20_000, 150_000]))
+            ks = universe[rng.integers(0, len(universe), m)]
+            vs = rng.integers(0, 2**32, m, dtype=np.uint32)
+            if op <= 2:
+                assert g.insert(dev(ks), dev(vs)) == o.insert(ks, vs)
+            elif op == 3:
+                assert g.insert(ks, vs) == o.insert(ks, vs)                       # host buffers
+            elif op == 4 and m <= 2000:
+                g.update(ks, vs)
+                for k, v in zip(ks.tolist(), vs.tolist()):
+                    o.update_one(k, v)
+            elif op == 5:
+                if m: check_queries(g, o, np.concatenate([ks, universe[:100] ^ np.uint64(1 << 63)]))
+            elif op == 6:
+                assert g.erase(dev(ks)) == o.erase(ks)
+            elif op == 7:
+                for k in ks[:5]:
+                    assert g.erase_one(int(k)) == o.erase_one(int(k))
+            elif op == 8:
+                r = int(rng.integers(0, usize)); g.reserve(r); o.reserve(r)
+            elif op == 9:
+                b = int(rng.choice([1024, 4096, 1 << 16, 1 << 18, 1 << 20]))
+                if o.size() <= b * min(mx, 0.5):
+                    g.rehash(b); o.rehash(b)
+            elif op == 10 and m:                                                  # streamed insert in 1..5 feeds
+                cuts = sorted(set([0, m] + [int(x) for x in rng.integers(0, m + 1, int(rng.integers(0, 5)))]))
+                g.insert_begin(m)
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    g.insert_feed(dev(ks[a:b]), dev(vs[a:b]))
+                assert g.insert_end() == o.insert(ks, vs)
+            elif op == 11 and rng.random() < 0.3:
+                g.clear(); o.clear()
+            elif op == 12:
+                f = float(rng.choice([0.5, 0.7, 0.8, 0.9]))
+                if f > mn: g.set_max_load_factor(f); o.set_max_load_factor(f); mx = f
+            check_state(g, o, kind)
+    except AssertionError as e:
+        import traceback; traceback.print_exc()
+        print("state: gpu size/cap", g.size(), g.capacity(), g.load_thresholds(), " oracle", o.size(), o.capacity(), o.min_load(), o.max_load(), "m", m)
+        print("FAIL seed", seed, "step", step, "op", op, "kind", kind, hname, mn, mx, cap0, usize, repr(e)[:300], flush=True)
+        sys.exit(1)
+    g.close()
+    runs += 1; seed += 1
+    if only_one: break
+print("soak ok: %d sequences of 40 steps, seeds up to %d" % (runs, seed - 1))

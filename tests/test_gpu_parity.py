@@ -463,6 +463,27 @@ def test_extreme_multiplicity_and_dense_chunks(oracle, kname, cls, kind):
 
 
 @pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_update_has_no_trailing_reserve(oracle, kname, cls, kind):
+    """found by scripts/soak_fuzz.py: insert(Iter,Iter) ends with reserve(size) (hashmap_robinhood.hpp:672), which grows a table
+    whose max load factor was lowered below its load; update(k,v) (:1274) does not, so neither does a batch of updates --
+    not even an empty one"""
+    keys = W.distinct_u64(20_000, seed=5)
+    vals = np.arange(len(keys), dtype=np.uint32)
+    g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals)
+    g.set_max_load_factor(0.5); o.set_max_load_factor(0.5)          # size 20000 > max_load(32768 * 0.5)
+    check_state(g, o, kind)
+    g.update(keys[:0], vals[:0])
+    check_state(g, o, kind)                                           # still capacity 32768
+    for k, v in zip(keys[:3].tolist(), (vals[:3] + 7).tolist()):     # existing keys: each update(k,v) is an insert call that doubles once
+        g.update(np.array([k], dtype=np.uint64), np.array([v], dtype=np.uint32)); o.update_one(k, v)
+        check_state(g, o, kind)
+    assert g.insert(dev(keys[:0]), dev(vals[:0])) == o.insert(keys[:0], vals[:0]) == 0     # the empty insert does end with reserve(size)
+    check_state(g, o, kind)
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
 def test_fused_build_long_probe_distances(oracle, kname, cls, kind):
     """bulk build with home buckets shared by 20..100 keys (identity hash, keys equal modulo the capacity): probe distances
     far beyond the 5-bit code the fused kernel keeps next to each staged record (>= 31 are re-derived from the key)"""
