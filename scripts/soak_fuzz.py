@@ -10,7 +10,8 @@ from oracle import oracle_py as O
 from test_gpu_parity import check_state, check_queries, dev
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-only_one = len(sys.argv) > 3
+only_one = len(sys.argv) > 3 and sys.argv[3] == "one"
+big = len(sys.argv) > 3 and sys.argv[3] == "big"          # multi-million-key batches: two-pass partitions, many chunks
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 KINDS = [(kh.hashmap_robinhood_doubling, 0), (kh.hashmap_linearprobe_doubling, 1)]
 HASHES = [("murmur3avx64", 1), ("murmur", 2), ("farm", 3)]
@@ -22,15 +23,15 @@ while time.time() < t_end:
     hname, hid = HASHES[int(rng.integers(0, 3))]
     mn = float(rng.choice([0.1, 0.35, 0.4])); mx = float(rng.choice([0.5, 0.7, 0.8, 0.9, 0.95]))
     cap0 = int(rng.choice([1, 128, 4096, 1 << 15]))
-    usize = int(rng.choice([3_000, 60_000, 600_000]))
+    usize = int(rng.choice([3_000, 60_000, 600_000])) if not big else int(rng.choice([2_000_000, 8_000_000]))
     g = cls(cap0, mn, mx, hash=hname, seed=43)
     o = O.OracleTable(kind, cap0, mn, mx, hid, 43)
     universe = W.splitmix64(np.arange(usize, dtype=np.uint64) + np.uint64(seed << 24))
     step = -1; op = -1
     try:
-        for step in range(40):
+        for step in range(40 if not big else 14):
             op = int(rng.integers(0, 13))
-            m = int(rng.choice([0, 1, 3, 50, 2000, 20_000, 150_000]))
+            m = int(rng.choice([0, 1, 3, 50, 2000, 20_000, 150_000])) if not big else int(rng.choice([0, 5, 2000, 300_000, 1_500_000, 4_000_000]))
             ks = universe[rng.integers(0, len(universe), m)]
             vs = rng.integers(0, 2**32, m, dtype=np.uint32)
             if op <= 2:
@@ -73,5 +74,6 @@ while time.time() < t_end:
         sys.exit(1)
     g.close()
     runs += 1; seed += 1
+    if big or runs % 100 == 0: print("seq", runs, "seed", seed - 1, "%.0f s left" % (t_end - time.time()), flush=True)
     if only_one: break
 print("soak ok: %d sequences of 40 steps, seeds up to %d" % (runs, seed - 1))
