@@ -149,6 +149,11 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t nranks,
  *      by '\n').  canonical != 0: min(k-mer, reverse complement).  out_kmers needs room for n entries. */
 kh_status kh_kmers_from_sequence(const void* seq /*[h|d] u8[n]*/, uint64_t n, uint32_t k /*1..32*/, int canonical, kh_mem where,
                                  uint64_t* out_kmers /*[h|d]*/, uint64_t* n_out, int device, void* hip_stream);
+/* the same over raw FASTQ text (BenchmarkKmerCounter.cpp:1476-1560 reads FASTQ through kmerind's FASTQParser, absent: PARITY
+ *      UNPINNED): records of 4 lines (@id, sequence, +, quality) starting at byte 0 of `text`; only the sequence lines
+ *      (line number 1 mod 4, counted by '\n') yield k-mers, a k-mer never spans two reads.  Pass whole records. */
+kh_status kh_kmers_from_fastq(const void* text /*[h|d] u8[n]*/, uint64_t n, uint32_t k /*1..32*/, int canonical, kh_mem where,
+                              uint64_t* out_kmers /*[h|d]*/, uint64_t* n_out, int device, void* hip_stream);
 
 /* ---- HyperLogLog cardinality estimator: fsc::hyperloglog64<T, Hash, precision> (hyperloglog64.hpp:142-475),
  *      64-bit hash values: register = top `precision` bits after dropping `ignore_msb` bits, rank = leading zeros + 1

@@ -20,7 +20,7 @@ SYMBOLS = [
     "kh_insert", "kh_insert_pairs", "kh_update", "kh_insert_reduce_plus", "kh_insert_begin", "kh_insert_feed", "kh_insert_end", "kh_count", "kh_find", "kh_find_compact", "kh_find_compact_pairs",
     "kh_erase", "kh_erase_one", "kh_to_vector", "kh_export_info", "kh_export_slots", "kh_displacement_histogram",
     "kh_hash_batch", "kh_shard_permute", "kh_profile_enable", "kh_profile_reset", "kh_profile_query", "kh_profile_dump",
-    "kh_kmers_from_sequence", "kh_hll_create", "kh_hll_destroy", "kh_hll_set_stream", "kh_hll_update", "kh_hll_update_via_hashval",
+    "kh_kmers_from_sequence", "kh_kmers_from_fastq", "kh_hll_create", "kh_hll_destroy", "kh_hll_set_stream", "kh_hll_update", "kh_hll_update_via_hashval",
     "kh_hll_merge", "kh_hll_clear", "kh_hll_registers", "kh_hll_estimate", "kh_release_cached_memory", "kh_version",
 ]
 
@@ -83,6 +83,7 @@ def lib():
     L.kh_shard_permute.argtypes = [i32, u64, u32, vp, vp, u64, vp, vp, vp, i32, vp]
     L.kh_release_cached_memory.argtypes = [i32]
     L.kh_kmers_from_sequence.argtypes = [vp, u64, u32, i32, i32, vp, pu64, i32, vp]
+    L.kh_kmers_from_fastq.argtypes = [vp, u64, u32, i32, i32, vp, pu64, i32, vp]
     L.kh_hll_create.argtypes = [C.POINTER(vp), u32, u32, i32, u64, i32]
     L.kh_hll_destroy.argtypes = [vp]
     L.kh_hll_set_stream.argtypes = [vp, vp]

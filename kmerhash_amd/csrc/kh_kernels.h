@@ -1605,3 +1605,41 @@ __global__ void k_kmers(const uint8_t* __restrict__ seq, uint64_t n, uint32_t k,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// FASTQ record structure on the device: records are 4 lines (@id, sequence, +, quality).  The line number of
+// every byte is the number of '\n' before it: tile sums + scan + an in-tile prefix.  Bytes that are not on a sequence line
+// (line % 4 != 1) become '\n', which the k-mer kernel treats as a run break -- so id / '+' / quality text (which may well
+// consist of the letters ACGT) never yields k-mers, and k-mers never span reads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_newline_tile_sums(const uint8_t* __restrict__ text, uint64_t n, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t wsum[4];
+  const uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE + (uint64_t)threadIdx.x * 8;
+  uint32_t c = 0;
+  for (int j = 0; j < 8; ++j) if (base + j < n && text[base + j] == '\n') ++c;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void k_fastq_mask(const uint8_t* __restrict__ text, uint64_t n, const uint64_t* __restrict__ tile_off,
+                                                    uint8_t* __restrict__ out) {
+  __shared__ uint32_t wtot[4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE + (uint64_t)tid * 8;
+  uint8_t c[8];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c[j] = base + j < n ? text[base + j] : (uint8_t)0; mine += c[j] == '\n' ? 1u : 0u; }
+  uint32_t incl = mine;
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += o; }
+  if (lane == 63) wtot[wid] = incl;
+  __syncthreads();
+  uint64_t line = tile_off[blockIdx.x] + (incl - mine);
+  for (uint32_t w = 0; w < wid; ++w) line += wtot[w];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (base + j < n) out[base + j] = ((line & 3u) == 1u && c[j] != '\n') ? c[j] : (uint8_t)'\n';
+    if (c[j] == '\n') ++line;
+  }
+}
+

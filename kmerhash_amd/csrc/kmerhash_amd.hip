@@ -1195,8 +1195,11 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64
 }
 
 // ---- k-mer generation front end ----------------------------------------------------------------------
-kh_status kh_kmers_from_sequence(const void* seq, uint64_t n, uint32_t k, int canonical, kh_mem where,
-                                 uint64_t* out_kmers, uint64_t* n_out, int device, void* stream_) {
+}  // extern "C"
+namespace {
+// shared body of kh_kmers_from_sequence / kh_kmers_from_fastq
+kh_status kmers_impl(const void* seq, uint64_t n, uint32_t k, int canonical, kh_mem where, bool fastq,
+                     uint64_t* out_kmers, uint64_t* n_out, int device, void* stream_) {
   kh_table* t = nullptr;
   if (n_out) *n_out = 0;
   if (k < 1 || k > 32 || !n_out) return KH_ERR_INVALID;
@@ -1205,15 +1208,17 @@ kh_status kh_kmers_from_sequence(const void* seq, uint64_t n, uint32_t k, int ca
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(device));
   const uint64_t ntl = (n + KH_CMP_TILE - 1) / KH_CMP_TILE;
-  // one pooled block: [seq copy (host input)] [all k-mers 8n] [flags n] [tile sums] [tile offsets] [compacted out (host output)]
+  // one pooled block: [text copy (host input)] [masked text (FASTQ)] [all k-mers 8n] [flags n] [tile sums] [tile offsets] [compacted out (host output)]
   const size_t sz_seq = where == KH_MEM_HOST ? ((n + 255) & ~size_t(255)) : 0;
+  const size_t sz_msk = fastq ? ((n + 255) & ~size_t(255)) : 0;
   const size_t sz_km = n * 8, sz_fl = (n + 255) & ~size_t(255), sz_sum = ((ntl * 4 + 255) & ~size_t(255)), sz_off = (ntl + 1) * 8;
   const size_t sz_out = where == KH_MEM_HOST ? n * 8 : 0;
   char* blk = nullptr;
-  HIPCHK(pool_alloc(device, sz_seq + sz_km + sz_fl + sz_sum + sz_off + 256 + sz_out, reinterpret_cast<void**>(&blk)));
+  HIPCHK(pool_alloc(device, sz_seq + sz_msk + sz_km + sz_fl + sz_sum + sz_off + 256 + sz_out, reinterpret_cast<void**>(&blk)));
   const uint8_t* dseq = static_cast<const uint8_t*>(seq);
   char* p = blk;
   if (where == KH_MEM_HOST) { dseq = reinterpret_cast<uint8_t*>(p); p += sz_seq; }
+  uint8_t* msk = reinterpret_cast<uint8_t*>(p); p += sz_msk;
   uint64_t* km = reinterpret_cast<uint64_t*>(p); p += sz_km;
   uint8_t* fl = reinterpret_cast<uint8_t*>(p); p += sz_fl;
   uint32_t* sums = reinterpret_cast<uint32_t*>(p); p += sz_sum;
@@ -1223,6 +1228,12 @@ kh_status kh_kmers_from_sequence(const void* seq, uint64_t n, uint32_t k, int ca
   if (where == KH_MEM_HOST) e = hipMemcpyAsync(const_cast<uint8_t*>(dseq), seq, n, hipMemcpyHostToDevice, stream);
   if (e == hipSuccess) e = hipMemsetAsync(fl, 0, sz_fl, stream);
   if (e == hipSuccess) {
+    if (fastq) {      // keep the sequence lines only (line number = newlines before the byte; sequence lines are 1 mod 4)
+      hipLaunchKernelGGL(k_newline_tile_sums, dim3((uint32_t)ntl), dim3(256), 0, stream, dseq, n, sums);
+      hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, stream, sums, ntl, offs);
+      hipLaunchKernelGGL(k_fastq_mask, dim3((uint32_t)ntl), dim3(256), 0, stream, dseq, n, offs, msk);
+      dseq = msk;
+    }
     const uint64_t strips = (n + KH_KMER_STRIP - 1) / KH_KMER_STRIP;
     const uint32_t grid = (uint32_t)((strips + 255) / 256);
     if (canonical) hipLaunchKernelGGL((k_kmers<true>), dim3(grid), dim3(256), 0, stream, dseq, n, k, km, fl);
@@ -1243,6 +1254,16 @@ kh_status kh_kmers_from_sequence(const void* seq, uint64_t n, uint32_t k, int ca
   if (e != hipSuccess) return KH_ERR_HIP;
   *n_out = total;
   return KH_OK;
+}
+}  // namespace
+extern "C" {
+kh_status kh_kmers_from_sequence(const void* seq, uint64_t n, uint32_t k, int canonical, kh_mem where,
+                                 uint64_t* out_kmers, uint64_t* n_out, int device, void* stream_) {
+  return kmers_impl(seq, n, k, canonical, where, false, out_kmers, n_out, device, stream_);
+}
+kh_status kh_kmers_from_fastq(const void* text, uint64_t n, uint32_t k, int canonical, kh_mem where,
+                              uint64_t* out_kmers, uint64_t* n_out, int device, void* stream_) {
+  return kmers_impl(text, n, k, canonical, where, true, out_kmers, n_out, device, stream_);
 }
 
 // ---- HyperLogLog (hyperloglog64.hpp) --------------------------------------------------------------

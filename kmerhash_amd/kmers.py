@@ -36,9 +36,17 @@ def sequences_from_fasta(buf):
     return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
 
 
-def kmers_from_sequence(seq, k=31, canonical=True, device=0):
+def kmers_from_fastq(text, k=31, canonical=True, device=0):
+    """raw FASTQ text (whole 4-line records; bytes / uint8 array on the host, or a uint8 CUDA tensor) -> packed k-mers of the
+    sequence lines: the record structure is resolved on the GPU (kh_kmers_from_fastq), no host-side parsing"""
+    return kmers_from_sequence(text, k, canonical, device, _fastq=True)
+
+
+def kmers_from_sequence(seq, k=31, canonical=True, device=0, _fastq=False):
     """-> packed k-mers (numpy uint64 for host input, torch int64 CUDA tensor for device input), sequence order"""
     L = K.lib()
+    if isinstance(seq, (bytes, bytearray)):
+        seq = np.frombuffer(seq, dtype=np.uint8)
     b = _Buf(seq, np.uint8, 1)
     n_out = C.c_uint64()
     if b.where == K.KH_MEM_DEVICE:
@@ -49,9 +57,10 @@ def kmers_from_sequence(seq, k=31, canonical=True, device=0):
         out = np.zeros(max(b.n, 1), dtype=np.uint64)
         optr = out.ctypes.data
         stream = None
-    st = L.kh_kmers_from_sequence(b.ptr, b.n, k, 1 if canonical else 0, b.where, optr, C.byref(n_out), device, stream)
+    fn = L.kh_kmers_from_fastq if _fastq else L.kh_kmers_from_sequence
+    st = fn(b.ptr, b.n, k, 1 if canonical else 0, b.where, optr, C.byref(n_out), device, stream)
     if st != K.KH_OK:
-        raise K.KhError(st, "kh_kmers_from_sequence")
+        raise K.KhError(st, "kh_kmers_from_fastq" if _fastq else "kh_kmers_from_sequence")
     return out[: n_out.value]
 
 
@@ -69,7 +78,11 @@ class KmerCounter:
         return len(km)
 
     def add_fastq(self, buf):
-        return self.add_sequences(sequences_from_fastq(buf))
+        """raw FASTQ text (whole records), host or device: record structure, k-mer generation and counting all run on the GPU"""
+        km = kmers_from_fastq(buf, self.k, self.canonical, self.device)
+        if len(km):
+            self.table.insert_reduce_plus(km)
+        return len(km)
 
     def counts(self):
         return self.table.to_vector()
@@ -129,3 +142,24 @@ def synthetic_read_sequences(n_reads, read_len=150, genome_len=1_000_000, seed=7
             blk[rng.integers(0, c1 - c0, n_n), rng.integers(0, read_len, n_n)] = ord("N")
     out[:, read_len] = 10
     return out.reshape(-1)
+
+
+def synthetic_fastq_fixed(n_reads, read_len=150, genome_len=1_000_000, seed=7, n_rate=0.001):
+    """raw FASTQ text of synthetic_read_sequences' reads (vectorised, fixed-width records: '@' + 11-digit id, sequence, '+',
+    quality 'I' * read_len), as a uint8 array -- the input shape of BenchmarkKmerCounter, for the GPU FASTQ path"""
+    seq = synthetic_read_sequences(n_reads, read_len, genome_len, seed, n_rate).reshape(n_reads, read_len + 1)
+    w = 1 + 11 + 1 + (read_len + 1) + 2 + (read_len + 1)
+    out = np.empty((n_reads, w), dtype=np.uint8)
+    out[:, 0] = ord("@")
+    ids = np.arange(n_reads, dtype=np.int64)
+    for d in range(11):
+        out[:, 11 - d] = ord("0") + (ids % 10)
+        ids //= 10
+    out[:, 12] = 10
+    out[:, 13: 13 + read_len + 1] = seq
+    o = 13 + read_len + 1
+    out[:, o] = ord("+"); out[:, o + 1] = 10
+    out[:, o + 2: o + 2 + read_len] = ord("I")
+    out[:, o + 2 + read_len] = 10
+    return out.reshape(-1)
+

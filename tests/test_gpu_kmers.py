@@ -73,6 +73,30 @@ def test_counter_on_synthetic_fastq(tmp_path):
     kc.close()
 
 
+@pytest.mark.parametrize("k", [3, 31])
+def test_fastq_record_structure_is_resolved_on_the_gpu(k):
+    """kh_kmers_from_fastq: only the sequence lines (line 1 mod 4) yield k-mers, although ids, '+' lines and quality strings
+    are written with the letters ACGT here; reads of varying length cross the 2048-byte tiles of the newline scan; the last
+    record has no trailing newline; compared with the host statement (split lines, take [1::4])"""
+    rng = np.random.default_rng(k)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    recs = []
+    for i in range(4000):
+        ln = int(rng.integers(0, 300))
+        seq = lut[rng.choice(5, ln, p=[.245, .245, .245, .245, .02])].tobytes()
+        qual = lut[rng.integers(0, 4, ln)].tobytes()                 # quality text that looks like bases
+        recs.append(b"@ACGTACGTACGTACGTACGTACGTACGTACGTACGT_" + str(i).encode() + b"\n" + seq + b"\n+ACGTACGTACGTACGTACGTACGTACGTACGT\n" + qual + b"\n")
+    fq = b"".join(recs)[:-1]
+    exp = np_kmers(KM.sequences_from_fastq(fq), k, True)
+    got = KM.kmers_from_fastq(fq, k, True)
+    assert np.array_equal(got, exp)
+    got_d = KM.kmers_from_fastq(torch.from_numpy(np.frombuffer(fq, dtype=np.uint8).copy()).cuda(), k, True)
+    assert np.array_equal(got_d.cpu().numpy().view(np.uint64), exp)
+    for cut in (0, 1, 5, 2047, 2048, 2049, 4096 + 17):                # truncated inputs: tile edges, mid-record ends
+        part = fq[:cut]
+        assert np.array_equal(KM.kmers_from_fastq(part, k, True), np_kmers(KM.sequences_from_fastq(part), k, True)), cut
+
+
 def test_fasta_sequences():
     fa = b">chr1 test\nACGTAC\nGTNNAC\n>chr2\nTTTTGGGGCC\n"
     s = KM.sequences_from_fasta(fa)
