@@ -120,7 +120,12 @@ class ShardedTable:
         return rk, rv, sc, rc
 
     # ---- batch operations (collective: every rank calls them) -----------------------------------------
-    def insert(self, keys, vals, chunks=1):
+    def insert_counts(self, keys, chunks=1):
+        """counting_batched_robinhood_map::insert(vector<Key>) (distributed_batched_robinhood_map.hpp:2542-2950): every key
+        occurrence adds 1 to its k-mer's count on the owner rank (Reducer = std::plus).  Same exchange as insert()."""
+        return self.insert(keys, None, chunks=chunks, reduce_plus=True)
+
+    def insert(self, keys, vals, chunks=1, reduce_plus=False):
         """insert_p :910-1194.  chunks == 1: shard, exchange, one bulk insert.
         chunks > 1: the RCCL analogue of khmxx::ialltoallv_and_modify (incremental_mxx.hpp:3437-3645).  The batch is cut into
         `chunks` pieces.  A count-only pass over every piece and ONE exchange of all the counts tell each rank exactly how
@@ -132,7 +137,7 @@ class ShardedTable:
         n = keys.numel()
         if chunks <= 1 or (self.p == 1 and not FORCE_COLLECTIVES) or not keys.is_cuda:
             rk, rv, _, _ = self._route(keys, vals)
-            return self.local.insert(rk, rv)
+            return self.local.insert_reduce_plus(rk, rv) if reduce_plus else self.local.insert(rk, rv)
         bounds = [n * i // chunks for i in range(chunks + 1)]
         # per-piece destination counts (count-only pass), one exchange for all of them: row = destination rank, column = piece
         sc_piece = [self.b.shard_counts(keys[bounds[i]:bounds[i + 1]], self.p) for i in range(chunks)]
@@ -143,20 +148,24 @@ class ShardedTable:
         dist.all_to_all_single(rc, sc.contiguous(), group=self.group)
         rc = rc.cpu().tolist()                                     # rc[src][piece]
         total = sum(sum(row) for row in rc)
-        self.local.insert_begin(total)
+        self.local.insert_begin(total, reduce_plus=reduce_plus)
         cur = torch.cuda.current_stream(self.b.torch_device)
         comm = torch.cuda.Stream(device=self.b.torch_device)
         keep, landed = [], None
         for i in range(chunks):
             a, b = bounds[i], bounds[i + 1]
-            ok, ov, scounts = self.b.shard(keys[a:b], vals[a:b], self.p)     # compute stream (stable permutation)
+            ok, ov, scounts = self.b.shard(keys[a:b], vals[a:b] if vals is not None else None, self.p)     # compute stream (stable permutation)
             rcounts = [rc[src][i] for src in range(self.p)]
             comm.wait_stream(cur)
             with torch.cuda.stream(comm):
                 rk = self._a2av(ok, scounts, rcounts)
-                rv = self._a2av(ov, scounts, rcounts)
-                ok.record_stream(comm); ov.record_stream(comm)
-                rk.record_stream(cur); rv.record_stream(cur)
+                rv = self._a2av(ov, scounts, rcounts) if ov is not None else None
+                for x in (ok, ov):
+                    if x is not None:
+                        x.record_stream(comm)
+                for x in (rk, rv):
+                    if x is not None:
+                        x.record_stream(cur)
                 ev = torch.cuda.Event()
                 ev.record(comm)
             if landed is not None:                                 # piece i-1: partition it while piece i travels

@@ -33,6 +33,18 @@ class OracleBackend:
             def insert(s, k, v):
                 return s.t.insert(k.numpy().view(np.uint64), v.numpy().view(np.uint32))
 
+            def insert_reduce_plus(s, k, v=None):
+                # Reducer = std::plus on the CPU model: existing keys are updated with old + count, new keys inserted with count
+                uk, cnt = np.unique(k.numpy().view(np.uint64), return_counts=True)
+                old, found = s.t.find(uk)
+                new = 0
+                for key, c, ov, f in zip(uk.tolist(), cnt.tolist(), old.tolist(), found.tolist()):
+                    if f:
+                        s.t.update_one(key, (ov + c) & 0xFFFFFFFF)
+                    else:
+                        new += s.t.insert(np.array([key], dtype=np.uint64), np.array([c], dtype=np.uint32))
+                return new
+
             def count(s, k):
                 return torch.from_numpy(s.t.count(k.numpy().view(np.uint64)))
 
@@ -115,6 +127,14 @@ def _worker(rank, world, port, q):
         got = fv.numpy().view(np.uint32)
         for i in np.nonzero(exp)[0][:2000]:
             assert got[i] == first[int(pkk[i])]
+        # counting insert (Reducer = std::plus): global multiplicities, each k-mer on its owner rank
+        sc = ShardedTable(OracleBackend(O, O.KIND_RH))
+        sc.insert_counts(tk)
+        sc.insert_counts(tk[:5000])
+        uk, cnt = np.unique(np.concatenate([a for a in allk] + [a[:5000] for a in allk]), return_counts=True)
+        mine = owner(uk) == rank
+        ck, cv = sc.local.t.sorted_items()
+        assert np.array_equal(ck, uk[mine]) and np.array_equal(cv, cnt[mine].astype(np.uint32))
         ne = st.erase(torch.from_numpy(keys[:1000].view(np.int64).copy()))
         tot = torch.tensor([ne])
         dist.all_reduce(tot)

@@ -72,6 +72,14 @@ def _worker(rank, world, port, q):
             assert np.array_equal(cnt.cpu().numpy(), exp)
             pk2, fv, ff = st.find(torch.from_numpy(qk.view(np.int64).copy()).cuda())
             assert np.array_equal(ff.cpu().numpy(), exp)
+            # counting insert through the same (pipelined) exchange: global multiplicities on the owner rank
+            sc = ShardedTable(GpuBackend(0))
+            sc.insert_counts(dk, chunks=chunks)
+            uk, ucnt = np.unique(np.concatenate(allk), return_counts=True)
+            mine = owner(uk) == rank
+            ck, cv = sc.local.sorted_items()
+            assert np.array_equal(ck, uk[mine]) and np.array_equal(cv, ucnt[mine].astype(np.uint32))
+            sc.local.close()
             ne = st.erase(dk[:5000])
             tot = torch.tensor([ne])
             dist.all_reduce(tot)
