@@ -226,7 +226,22 @@ def main():
         table.close()
         return state
 
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        if distributed and w == 0 and args.chunks > 1:
+            # safety net for the pipelined exchange (it cannot be rehearsed with real peers on a one-GPU box): if any rank fails
+            # its first warm-up step, every rank falls back to exchange-then-insert for the rest of the run
+            ok = 1
+            try:
+                one_step(False)
+            except Exception as ex:           # noqa: BLE001
+                print("[bench] rank %d: pipelined insert failed (%r), falling back to --chunks 1" % (rank, ex), file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                args.chunks = 1
+                one_step(False)
+            continue
         one_step(False)
     barrier()
     t0 = time.perf_counter()
