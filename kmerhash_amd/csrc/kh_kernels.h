@@ -891,20 +891,30 @@ __device__ __forceinline__ void kh_for_each_old(const KhRebuildParams& P, uint32
   const uint32_t ostep = nch_o >= nch_n ? nch_n : nch_o;   // second form: exactly one iteration
   for (; o < nch_o; o += ostep) {
     const uint64_t S = (uint64_t)o * Lo;
-    __syncthreads();
-    if (tid == 0) *s_emin = spill_max;
-    __syncthreads();
-    for (uint32_t t = tid; t < spill_max; t += KH_CHUNK_THREADS) {
-      if (kh_is_empty<KIND>(P.Old.info[(S + Lo + t) & mask_o])) { atomicMin(s_emin, t); break; }
+    // how far behind the chunk its elements can sit.  Robin Hood: the probe distance is at most 127.  Linear probing: up to
+    // the first empty slot -- searched window by window, because a run of occupied slots can be longer than a chunk at high
+    // load (load 0.9, 10^7 elements: runs of ~3000 slots) and an element may have been pushed to its very end.
+    uint64_t e_total = 0;
+    const uint64_t beyond = cap_o - Lo;
+    if (KIND == KHK_RH) e_total = beyond < 128u ? beyond : 128u;
+    else {
+      for (uint64_t base = 0; base < beyond; base += KH_L) {
+        const uint32_t window = beyond - base < KH_L ? (uint32_t)(beyond - base) : KH_L;
+        __syncthreads();
+        if (tid == 0) *s_emin = window;
+        __syncthreads();
+        for (uint32_t t = tid; t < window; t += KH_CHUNK_THREADS) {
+          if (kh_is_empty<KIND>(P.Old.info[(S + Lo + base + t) & mask_o])) { atomicMin(s_emin, t); break; }
+        }
+        __syncthreads();
+        const uint32_t e = *s_emin;
+        e_total = base + e;
+        if (e < window) break;
+      }
     }
-    __syncthreads();
-    const uint32_t e = *s_emin;
-    if (e == spill_max && spill_max > 0 && tid == 0) {
-      // no empty slot within a whole chunk after this one: only possible for clusters longer than KH_L
-      if (spill_max == KH_L) atomicOr(&P.flags[KH_FLAG_REGION_OVERFLOW], 1u);
-    }
-    const uint32_t len = Lo + e;
-    for (uint32_t t = tid; t < len; t += KH_CHUNK_THREADS) {
+    (void)spill_max;
+    const uint64_t len = (uint64_t)Lo + e_total;
+    for (uint64_t t = tid; t < len; t += KH_CHUNK_THREADS) {
       const uint64_t s = (S + t) & mask_o;
       if (!kh_is_occupied<KIND>(P.Old.info[s])) continue;
       if (P.erased_bits && ((P.erased_bits[s >> 5] >> (s & 31)) & 1u)) continue;
@@ -1136,8 +1146,57 @@ struct KhFusedParams {
   unsigned long long* est;                               // [0] distinct so far << 32 | records so far (ONE word: the pair must be
                                                          //     read consistently), [1] abort
   uint32_t* flags;
+  KhRebuildParams R;                                     // SRC == 1 only: source table, erase mask, new distinct elements
 };
-template <int KIND, int HASH>
+
+// SRC == 1 (Robin Hood): the chunk's elements come from the CURRENT table (same capacity or half of the new one) plus the
+// batch's new distinct keys, instead of from partition records -- the one-launch form of k_chunk_count + k_chunk_carry +
+// k_chunk_place for erase, rehash/reserve and inserts into a non-empty table.  An element with home bucket in old chunk o
+// sits in a slot of [S_o, S_o + L + 128) (probe distance <= 127) and carries its home in the info byte (slot - distance):
+// no hash is evaluated unless the capacity doubles (one more hash bit is needed then).  Staged as
+// lk[x] = key, liv[x] = (home - chunk start) << 32 | value; the elements are distinct, so there is nothing to fold.
+// Returns the number of staged elements (may exceed the staging area: the caller gives up then).
+template <int HASH>
+__device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R, uint32_t c, uint64_t Sc, unsigned long long* lk,
+                                                         unsigned long long* liv, uint32_t* n_staged) {
+  const uint32_t tid = threadIdx.x;
+  const uint64_t cap_o = R.Old.cap, mask_o = cap_o - 1, mask_n = R.New.cap - 1;
+  if (tid == 0) *n_staged = 0;
+  __syncthreads();
+  if (cap_o) {
+    const uint32_t nch_o = (uint32_t)(cap_o >> KH_LB);       // host: cap_o >= 2 * KH_L and New.cap in {cap_o, 2 * cap_o}
+    const uint32_t o = c & (nch_o - 1);
+    const bool same = R.New.cap == cap_o;
+    const uint64_t S = (uint64_t)o * KH_L;
+    for (uint32_t t0 = 0; t0 < KH_L + 128u; t0 += KH_CHUNK_THREADS) {
+      const uint32_t t = t0 + tid;
+      bool take = false;
+      uint64_t key = 0; uint32_t val = 0, hrel = 0;
+      if (t < KH_L + 128u) {
+        const uint64_t sl = (S + t) & mask_o;
+        const uint32_t inf = R.Old.info[sl];
+        if (inf >= 0x80u && !(R.erased_bits && ((R.erased_bits[sl >> 5] >> (sl & 31)) & 1u))) {
+          const uint64_t home_o = (sl - (inf & 0x7Fu)) & mask_o;
+          if ((uint32_t)(home_o >> KH_LB) == o) {
+            key = R.Old.keys[sl];
+            const uint64_t hn = same ? home_o : (kh_hash64<HASH>(key, R.seed) & mask_n);
+            if ((uint32_t)(hn >> KH_LB) == c) { take = true; val = R.Old.vals[sl]; hrel = (uint32_t)(hn - Sc); }
+          }
+        }
+      }
+      const uint32_t x = kh_wave_append(take, n_staged);
+      if (take && x < KH_DD_M) { lk[x] = key; liv[x] = ((unsigned long long)hrel << 32) | val; }
+    }
+  }
+  kh_for_each_new<HASH>(R, c, [&](uint64_t key, uint32_t val, uint64_t hn) {
+    const uint32_t x = kh_wave_append(true, n_staged);
+    if (x < KH_DD_M) { lk[x] = key; liv[x] = ((unsigned long long)(uint32_t)(hn - Sc) << 32) | val; }
+  });
+  __syncthreads();
+  return *n_staged;
+}
+
+template <int KIND, int HASH, int SRC>
 __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams P) {
   __shared__ unsigned long long lk[KH_DD_M];
   __shared__ unsigned long long liv[KH_DD_M];
@@ -1157,7 +1216,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   if (tid == 0) {
     s_chunk = blockIdx.x;
     s_max = 0;
-    s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_abort = SRC == 0 ? (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   }
   __syncthreads();
   // the source table of a streamed insert lives in simg[] until the records are staged: every byte of LDS counts here
@@ -1166,29 +1225,46 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   uint32_t* s_cum = reinterpret_cast<uint32_t*>(simg) + 2 * KH_MAX_SRC;
   static_assert((KH_L + KH_FSPILL) * 2 >= KH_MAX_SRC * 8 + (KH_MAX_SRC + 1) * 4, "source table fits the image array");
   const uint32_t c = s_chunk;
-  const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
-  const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
-  const uint32_t m = V.m;
   const uint64_t Sc = (uint64_t)c * KH_L;
   const unsigned long long VALID = 1ull << 63;
-  const bool aborted = s_abort != 0;
+  uint32_t m, rep_mask;
   // (record indices travel as 11-bit fields next to a 5-bit distance code, 0xFFFF = empty slot: index 2047 stays unused)
-  if (m >= KH_DD_M || aborted) {     // does not fit the staging area / speculation given up: general path
-    if (tid == 0) {
-      // (an aborted launch was flagged once by the workgroup that gave up: 65 K atomics on one word would cost 2 ms)
-      if (!aborted) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
-      __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (SRC == 0) {
+    const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
+    const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
+    m = V.m;
+    const bool aborted = s_abort != 0;
+    if (m >= KH_DD_M || aborted) {     // does not fit the staging area / speculation given up: general path
+      if (tid == 0) {
+        // (an aborted launch was flagged once by the workgroup that gave up: 65 K atomics on one word would cost 2 ms)
+        if (!aborted) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+        __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
     }
-    return;
+    // ---- de-dup (as k_dedup, single round)
+    for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+    for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = kh_src_load(V, s_ptr, s_cum, i); lk[i] = rr.x; liv[i] = rr.y; }
+    if (V.n > 1) __syncthreads();       // the source table (in simg[]) has been read by every lane
+    for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
+    __syncthreads();
+    rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
+    __syncthreads();
+  } else {
+    m = kh_stage_from_table<HASH>(P.R, c, Sc, lk, liv, &s_x);
+    if (m >= KH_DD_M) {                // denser than the staging area: general path
+      if (tid == 0) {
+        atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+        __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
+    rep_mask = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) if (it * KH_CHUNK_THREADS + tid < m) rep_mask |= 1u << it;
+    __syncthreads();
   }
-  // ---- de-dup (as k_dedup, single round)
-  for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
-  for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = kh_src_load(V, s_ptr, s_cum, i); lk[i] = rr.x; liv[i] = rr.y; }
-  if (V.n > 1) __syncthreads();       // the source table (in simg[]) has been read by every lane
-  for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
-  __syncthreads();
-  const uint32_t rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
-  __syncthreads();
   // ---- home counts of the distinct keys (set[] is dead from here on)
   for (uint32_t i = tid; i < 2 * KH_L; i += KH_CHUNK_THREADS) set[i] = 0;
   __syncthreads();
@@ -1199,9 +1275,9 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     hb[it] = 0;
     const uint32_t x = it * KH_CHUNK_THREADS + tid;
     if ((rep_mask >> it) & 1u) {
-      hb[it] = (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc);
+      hb[it] = SRC == 0 ? (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc) : (uint32_t)(liv[x] >> 32);
       atomicAdd(&cnt[hb[it]], 1u);
-      if (P.mode == KH_DEDUP_FIRST) { const uint32_t ix = (uint32_t)(liv[x] >> 32) + 1u; my_max = ix > my_max ? ix : my_max; }
+      if (SRC == 0 && P.mode == KH_DEDUP_FIRST) { const uint32_t ix = (uint32_t)(liv[x] >> 32) + 1u; my_max = ix > my_max ? ix : my_max; }
     }
   }
   my_max = kh_wave_max(my_max);
@@ -1241,7 +1317,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   }
   // ---- publish / look back
   if (tid == 0) {
-    if (c < 64) {     // the first 64 chunks vote on the duplicate ratio (same-address atomics are kept off the other 65 K)
+    if (SRC == 0 && c < 64) {     // the first 64 chunks vote on the duplicate ratio (same-address atomics are kept off the other 65 K)
       const unsigned long long mine = ((unsigned long long)n_c << 32) | m;
       const unsigned long long tot = atomicAdd(&P.est[0], mine) + mine;      // < 64 * 2048 records: the low word cannot carry
       const uint32_t sn = (uint32_t)(tot >> 32), sm = (uint32_t)tot;

@@ -303,6 +303,8 @@ inline size_t ws_rebuild(uint64_t cap) { return size_t(cap) * 2 + (cap > KH_L ? 
 // a fresh buffer and makes it current.  On KH_ERR_* the current table is unchanged.
 struct PreCount { uint16_t* homecnt; long long* sumA; long long* sumN; };   // chunk counts already produced by k_dedup
 
+const bool g_disable_fused_rebuild = getenv("KH_DISABLE_FUSED_BUILD") != nullptr || getenv("KH_DISABLE_FUSED_REBUILD") != nullptr;   // test hooks
+
 kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint32_t* cv, const uint64_t* noff,
                   const uint32_t* ncnt, uint32_t PB, const uint32_t* erased, uint64_t total_after, const PreCount* pre = nullptr) {
   if (total_after > new_cap)
@@ -311,6 +313,70 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
   kh_status st = fresh_slots(t, new_cap, nw);
   if (st != KH_OK) return st;
   const uint32_t nch = new_cap > KH_L ? (uint32_t)(new_cap >> KH_LB) : 1u;
+  // ---- one-launch rebuild (k_build_fused with the current table as its source): Robin Hood, same or doubled capacity.
+  // Speculative like the bulk build: a chunk denser than the staging area, a carry chain or a poll time-out raise a flag,
+  // and the three-kernel path below redoes the work into the same buffer.
+  if (t->kind == KHK_RH && t->lsize > 0 && !pre && !g_disable_fused_rebuild && t->cur.cap >= 2 * (uint64_t)KH_L &&
+      (new_cap == t->cur.cap || new_cap == 2 * t->cur.cap) && total_after <= threshold(new_cap, 0.9f) &&
+      (!noff || PB >= log2u(new_cap >> KH_LB))) {
+    const size_t keep_blk = t->blk, keep_off = t->off;
+    char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
+    const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
+    TAKE(blk, char, sz_all);
+    TAKE(maxidx, uint32_t, nch);
+    TAKE(ck0, uint64_t, KH_DD_M); TAKE(cv0, uint32_t, KH_DD_M); TAKE(hc0, uint16_t, KH_L); TAKE(xc0, long long, 1);
+    TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
+    HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
+    HIPCHK(hipMemsetAsync(maxidx, 0, sizeof(uint32_t) * nch, t->stream));
+    KhFusedParams F;
+    memset(&F, 0, sizeof(F));
+    F.PB = PB; F.New = nw; F.seed = t->seed; F.mode = KH_DEDUP_FIRST;
+    F.pub = reinterpret_cast<unsigned long long*>(blk);
+    unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);
+    F.maxidx = maxidx; F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
+    F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);
+    F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);
+    F.R.Old = t->cur; F.R.erased_bits = erased; F.R.New = nw; F.R.ck = ck; F.R.cv = cv; F.R.noff = noff; F.R.ncnt = ncnt; F.R.PB = PB;
+    F.R.seed = t->seed; F.R.flags = F.flags;
+    { Launch L(t, "k_rebuild_fused");
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    { Launch L(t, "k_fused_totals");
+      hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
+    { Launch L(t, "k_fused_tail");
+      hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);
+      HIPCHK(hipMemsetAsync(noff0, 0, 16, t->stream));
+      HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
+      KhRebuildParams T0;
+      memset(&T0, 0, sizeof(T0));
+      T0.Old = KhSlots{nullptr, nullptr, nullptr, 0}; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0;
+      T0.PB = log2u(new_cap >> KH_LB);       // the parked list is chunk 0's own: one partition per chunk
+      T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_chunk_place<KHK_RH, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    const uint32_t* ff = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 64);
+    bool bad = false;
+    for (int i = 0; i < KH_NFLAGS; ++i) bad = bad || ff[i] != 0;
+    if (!bad && t->hpin[0] == total_after) {
+      KhSlots old = t->cur;
+      t->cur = nw;
+      retire_slots(t, old);
+      t->min_load = threshold(new_cap, t->min_lf);
+      t->max_load = threshold(new_cap, t->max_lf);
+      return KH_OK;
+    }
+    if (getenv("KH_DEBUG_FUSED"))
+      fprintf(stderr, "[kmerhash_amd] fused rebuild rejected: placed %llu expected %llu flags=%u %u %u %u %u\n", (unsigned long long)t->hpin[0],
+              (unsigned long long)total_after, ff[0], ff[1], ff[2], ff[3], ff[4]);
+    if (ff[KH_FLAG_PROBE_OVERFLOW] && !ff[KH_FLAG_FUSE_INVALID]) {   // a genuine 7-bit overflow: the general path would find the same
+      KhSlots tmp = nw;
+      retire_slots(t, tmp);
+      return fail(t, KH_ERR_PROBE_OVERFLOW, "Robin Hood probe distance would exceed 127 (7-bit info field, hashmap_robinhood.hpp:142-144,556)");
+    }
+    t->blk = keep_blk; t->off = keep_off;      // scratch of the failed attempt is reused by the general path
+  }
   uint16_t* homecnt; long long *sumA, *sumN, *xcarry; KhMP* ptmp; uint32_t* flags;
   if (pre) { homecnt = pre->homecnt; sumA = pre->sumA; sumN = pre->sumN; }
   else { TAKE(homecnt, uint16_t, new_cap); TAKE(sumA, long long, nch); TAKE(sumN, long long, nch); }
@@ -537,11 +603,12 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
     F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);          // 2 x u64
     F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);                  // KH_NFLAGS x u32
+    memset(&F.R, 0, sizeof(F.R));
     F.n_total = n;
     // giving up early only makes sense if a smaller capacity is possible at all (an insert never shrinks the table)
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
     { Launch L(t, "k_build_fused");
-      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 0>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     { Launch L(t, "k_fused_totals");
       hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
     { // chunk 0: placed now that the last chunk's run-over is known (one workgroup of the general placement kernel)

@@ -67,8 +67,9 @@ while time.time() < t_end:
                 f = float(rng.choice([0.5, 0.7, 0.8, 0.9]))
                 if f > mn: g.set_max_load_factor(f); o.set_max_load_factor(f); mx = f
             check_state(g, o, kind)
-    except AssertionError as e:
+    except (AssertionError, Exception) as e:
         import traceback; traceback.print_exc()
+        print("oracle probe_overflow:", o.probe_overflow())
         print("state: gpu size/cap", g.size(), g.capacity(), g.load_thresholds(), " oracle", o.size(), o.capacity(), o.min_load(), o.max_load(), "m", m)
         print("FAIL seed", seed, "step", step, "op", op, "kind", kind, hname, mn, mx, cap0, usize, repr(e)[:300], flush=True)
         sys.exit(1)

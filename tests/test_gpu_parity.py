@@ -463,6 +463,35 @@ def test_extreme_multiplicity_and_dense_chunks(oracle, kname, cls, kind):
 
 
 @pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_high_load_runs_longer_than_a_chunk(oracle, kname, cls, kind):
+    """found by scripts/soak_fuzz.py: at load 0.94 a 2^22-bucket table holds runs of occupied slots far longer than one
+    2048-slot chunk (probe distances stay small); re-laying out such a table (second insert, erase, rehash) must not depend
+    on finding an empty slot within a chunk's length"""
+    n = 3_940_000
+    keys = W.distinct_u64(n, seed=19)
+    vals = np.arange(n, dtype=np.uint32)
+    g = cls(1 << 15, 0.35, 0.95, hash="murmur", seed=43)
+    o = oracle.OracleTable(kind, 1 << 15, 0.35, 0.95, 2, 43)
+    a = 3_000_000
+    assert g.insert(dev(keys[:a]), dev(vals[:a])) == o.insert(keys[:a], vals[:a])
+    assert g.insert(dev(keys[a:]), dev(vals[a:])) == o.insert(keys[a:], vals[a:])          # into a non-empty table at load 0.72 -> 0.94
+    if kind == 0 and o.probe_overflow():
+        pytest.skip("the reference itself overflows its 7-bit distance here")
+    info = o.export_info()
+    occ = (info >= 0x80) if kind == 0 else (info < 0x40)
+    runs = np.diff(np.flatnonzero(np.concatenate([[True], ~occ, [True]])))
+    assert runs.max() > 2048, runs.max()                                                   # the situation under test
+    check_state(g, o, kind)
+    extra = W.distinct_u64(5, seed=23)
+    assert g.insert(dev(extra), dev(vals[:5])) == o.insert(extra, vals[:5])                # one more re-layout of the dense table
+    check_state(g, o, kind)
+    assert g.erase(dev(keys[:100_000])) == o.erase(keys[:100_000])
+    check_state(g, o, kind)
+    check_queries(g, o, np.concatenate([keys[99_000:101_000], extra]))
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
 def test_update_has_no_trailing_reserve(oracle, kname, cls, kind):
     """found by scripts/soak_fuzz.py: insert(Iter,Iter) ends with reserve(size) (hashmap_robinhood.hpp:672), which grows a table
     whose max load factor was lowered below its load; update(k,v) (:1274) does not, so neither does a batch of updates --
