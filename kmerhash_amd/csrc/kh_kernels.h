@@ -1156,7 +1156,10 @@ struct KhFusedParams {
 // no hash is evaluated unless the capacity doubles (one more hash bit is needed then).  Staged as
 // lk[x] = key, liv[x] = (home - chunk start) << 32 | value; the elements are distinct, so there is nothing to fold.
 // Returns the number of staged elements (may exceed the staging area: the caller gives up then).
-template <int HASH>
+// MERGE (SRC == 2): the staged table elements will be folded together with the batch's records of this chunk, so they
+// carry iv = 0 << 32 | value (stream position field 0: an element of the table beats every record of the batch, whose
+// position fields are shifted up by one) and the new distinct lists are not read.
+template <int HASH, bool MERGE>
 __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R, uint32_t c, uint64_t Sc, unsigned long long* lk,
                                                          unsigned long long* liv, uint32_t* n_staged) {
   const uint32_t tid = threadIdx.x;
@@ -1185,13 +1188,14 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
         }
       }
       const uint32_t x = kh_wave_append(take, n_staged);
-      if (take && x < KH_DD_M) { lk[x] = key; liv[x] = ((unsigned long long)hrel << 32) | val; }
+      if (take && x < KH_DD_M) { lk[x] = key; liv[x] = MERGE ? (unsigned long long)val : (((unsigned long long)hrel << 32) | val); }
     }
   }
-  kh_for_each_new<HASH>(R, c, [&](uint64_t key, uint32_t val, uint64_t hn) {
-    const uint32_t x = kh_wave_append(true, n_staged);
-    if (x < KH_DD_M) { lk[x] = key; liv[x] = ((unsigned long long)(uint32_t)(hn - Sc) << 32) | val; }
-  });
+  if (!MERGE)
+    kh_for_each_new<HASH>(R, c, [&](uint64_t key, uint32_t val, uint64_t hn) {
+      const uint32_t x = kh_wave_append(true, n_staged);
+      if (x < KH_DD_M) { lk[x] = key; liv[x] = ((unsigned long long)(uint32_t)(hn - Sc) << 32) | val; }
+    });
   __syncthreads();
   return *n_staged;
 }
@@ -1250,8 +1254,31 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     __syncthreads();
     rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
     __syncthreads();
+  } else if (SRC == 2) {
+    // ---- insert into a non-empty table: the chunk's current elements + the batch's records of this chunk, folded together
+    const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
+    const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
+    for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+    const uint32_t n_old = kh_stage_from_table<HASH, true>(P.R, c, Sc, lk, liv, &s_x);     // (ends with a barrier)
+    m = n_old + V.m;
+    if (n_old >= KH_DD_M || m >= KH_DD_M) {
+      if (tid == 0) {
+        atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+        __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    for (uint32_t i = tid; i < V.m; i += KH_CHUNK_THREADS) {
+      const ulonglong2 rr = kh_src_load(V, s_ptr, s_cum, i);
+      lk[n_old + i] = rr.x; liv[n_old + i] = rr.y + (1ull << 32);       // position + 1: 0 is "already in the table"
+    }
+    if (V.n > 1) __syncthreads();
+    for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
+    __syncthreads();
+    rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
+    __syncthreads();
   } else {
-    m = kh_stage_from_table<HASH>(P.R, c, Sc, lk, liv, &s_x);
+    m = kh_stage_from_table<HASH, false>(P.R, c, Sc, lk, liv, &s_x);
     if (m >= KH_DD_M) {                // denser than the staging area: general path
       if (tid == 0) {
         atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
@@ -1275,9 +1302,11 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     hb[it] = 0;
     const uint32_t x = it * KH_CHUNK_THREADS + tid;
     if ((rep_mask >> it) & 1u) {
-      hb[it] = SRC == 0 ? (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc) : (uint32_t)(liv[x] >> 32);
+      hb[it] = SRC != 1 ? (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc) : (uint32_t)(liv[x] >> 32);
       atomicAdd(&cnt[hb[it]], 1u);
+      // position + 1 of the first occurrence of a NEW key (SRC 2: the field is already shifted, 0 = the key was in the table)
       if (SRC == 0 && P.mode == KH_DEDUP_FIRST) { const uint32_t ix = (uint32_t)(liv[x] >> 32) + 1u; my_max = ix > my_max ? ix : my_max; }
+      if (SRC == 2 && P.mode == KH_DEDUP_FIRST) { const uint32_t ix = (uint32_t)(liv[x] >> 32); my_max = ix > my_max ? ix : my_max; }
     }
   }
   my_max = kh_wave_max(my_max);

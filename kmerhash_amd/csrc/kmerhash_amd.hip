@@ -658,6 +658,77 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
               reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[2]);
     retire_slots(t, nw);      // speculation failed (duplicates, skew): the buffer becomes the spare, general path below
   }
+  // ---- fused insert into a NON-empty Robin Hood table: every chunk stages its current elements (home from the info byte)
+  // next to the batch's records of the same chunk, folds them together (an element of the table beats every record), and
+  // lays the chunk out -- no membership probes at random into HBM (k_dedup), no separate re-layout.  Speculates, like the
+  // bulk build, that the capacity the reference's rule yields equals cap_u.
+  if (t->lsize > 0 && t->kind == KHK_RH && (mode == INS_FIRST || mode == INS_PLUS) && !forced_cap && !g_disable_fused_rebuild &&
+      t->cur.cap >= 2 * (uint64_t)KH_L && (cap_u == t->cur.cap || cap_u == 2 * t->cur.cap) && t->max_lf <= 0.9f &&
+      PB == log2u(cap_u >> KH_LB) && t->lsize + n <= threshold(cap_u, 0.92f)) {
+    const size_t keep_blk = t->blk, keep_off = t->off;
+    const uint32_t nch = (uint32_t)(cap_u >> KH_LB);
+    KhSlots nw;
+    st = fresh_slots(t, cap_u, nw);
+    if (st != KH_OK) return st;
+    char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
+    const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
+    TAKE(blk, char, sz_all);
+    TAKE(maxidx, uint32_t, nch);
+    TAKE(ck0, uint64_t, KH_DD_M); TAKE(cv0, uint32_t, KH_DD_M); TAKE(hc0, uint16_t, KH_L); TAKE(xc0, long long, 1);
+    TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
+    HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
+    HIPCHK(hipMemsetAsync(maxidx, 0, sizeof(uint32_t) * nch, t->stream));
+    KhFusedParams F;
+    memset(&F, 0, sizeof(F));
+    F.src = S; F.PB = PB; F.New = nw; F.seed = t->seed;
+    F.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST;
+    F.pub = reinterpret_cast<unsigned long long*>(blk);
+    unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);
+    F.maxidx = maxidx; F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
+    F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);
+    F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);
+    F.n_total = n;
+    F.R.Old = t->cur; F.R.New = nw; F.R.PB = PB; F.R.seed = t->seed; F.R.flags = F.flags;
+    { Launch L(t, "k_insert_fused");
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    { Launch L(t, "k_fused_totals");
+      hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
+    { Launch L(t, "k_fused_tail");
+      hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);
+      HIPCHK(hipMemsetAsync(noff0, 0, 16, t->stream));
+      HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
+      KhRebuildParams T0;
+      memset(&T0, 0, sizeof(T0));
+      T0.Old = KhSlots{nullptr, nullptr, nullptr, 0}; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
+      T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_chunk_place<KHK_RH, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    const uint64_t total = t->hpin[0];
+    const uint64_t fd = total >= t->lsize ? total - t->lsize : 0;
+    const uint64_t flast = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
+    const uint32_t* ff = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 64);
+    bool bad = total < t->lsize;
+    for (int i = 0; i < KH_NFLAGS; ++i) bad = bad || ff[i] != 0;
+    if (!bad && capacity_after(t, t->cur.cap, t->lsize, n, fd, flast) == cap_u) {
+      KhSlots old = t->cur;
+      t->cur = nw;
+      retire_slots(t, old);
+      t->min_load = threshold(cap_u, t->min_lf);
+      t->max_load = threshold(cap_u, t->max_lf);
+      t->lsize = total;
+      *n_new_out = fd;
+      return KH_OK;
+    }
+    if (getenv("KH_DEBUG_FUSED"))
+      fprintf(stderr, "[kmerhash_amd] fused insert rejected: n=%llu size=%llu total=%llu cap_u=%llu cap_rule=%llu flags=%u %u %u %u %u\n", (unsigned long long)n,
+              (unsigned long long)t->lsize, (unsigned long long)total, (unsigned long long)cap_u,
+              (unsigned long long)capacity_after(t, t->cur.cap, t->lsize, n, fd, flast), ff[0], ff[1], ff[2], ff[3], ff[4]);
+    retire_slots(t, nw);
+    t->blk = keep_blk; t->off = keep_off;
+  }
   uint32_t* cnt_new; uint64_t* noff; unsigned long long* scal; uint32_t* flags;
   TAKE(cnt_new, uint32_t, R.nparts); TAKE(noff, uint64_t, R.nparts + 1); TAKE(scal, unsigned long long, 4);
   TAKE(flags, uint32_t, KH_NFLAGS);

@@ -1,0 +1,18 @@
+"""cost of inserting into a NON-empty table (general path: de-dup + re-layout of the whole table): two batches of 5e7 keys"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+import kmerhash_amd as kh
+from kmerhash_amd import workloads as W
+n = 100_000_000
+dk = torch.from_numpy(W.distinct_u64(n, seed=1).view(np.int64)).cuda(); dv = torch.arange(n, device="cuda", dtype=torch.int32)
+for rep in range(3):
+    t = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    t.insert(dk[: n // 2], dv[: n // 2])
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    t.profile_enable(True)
+    t.insert(dk[n // 2:], dv[n // 2:])
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("first 5e7: %.2f ms  second 5e7 (into 5e7): %.2f ms  cap %d" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, t.capacity()), {k: round(v[1], 2) for k, v in t.profile().items() if v[1] > 0.05}, flush=True)
+    t.close()
