@@ -366,6 +366,50 @@ def test_bulk_build_into_empty_table_fused_path(oracle, kname, cls, kind, hname,
     g.close(); g2.close()
 
 
+@pytest.mark.parametrize("hname,hid", HASHES)
+def test_one_launch_relayouts_of_a_robin_hood_table(oracle, hname, hid):
+    """the re-layouts of a non-empty RH table take the one-launch kernels and stay bit-exact: a second batch (k_insert_fused:
+    table elements and batch records folded in LDS; 10 % of the batch repeats keys of the table, 3 % repeats itself), an erase
+    (k_rebuild_fused at equal capacity: home bucket from the info byte), a doubling rehash and a reserve"""
+    n = 380_000          # 200 000 in the table + 200 000 records (180 000 new): predicted and actual capacity are both 2^19
+    keys = W.distinct_u64(n, seed=31)
+    if hname == "identity":
+        keys = W.splitmix64(keys)
+    vals = np.arange(n, dtype=np.uint32)
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=hname, seed=43)
+    o = oracle.OracleTable(0, 128, 0.35, 0.8, hid, 43)
+    a = 200_000
+    assert g.insert(dev(keys[:a]), dev(vals[:a])) == o.insert(keys[:a], vals[:a])
+    k2 = np.concatenate([keys[a:], keys[:15_000], keys[a:a + 5_000]])
+    k2 = k2[np.random.default_rng(4).permutation(len(k2))]
+    v2 = np.arange(len(k2), dtype=np.uint32) + np.uint32(1_000_000)
+    g.profile_enable(True)
+    assert g.insert(dev(k2), dev(v2)) == o.insert(k2, v2) == n - a
+    assert "k_insert_fused" in g.profile() and "k_dedup" not in g.profile(), g.profile()
+    check_state(g, o, 0)
+    g.profile_reset()
+    assert g.erase(dev(keys[100_000:180_000])) == o.erase(keys[100_000:180_000]) == 80_000
+    assert "k_rebuild_fused" in g.profile() and "k_chunk_place" not in g.profile(), g.profile()
+    check_state(g, o, 0)
+    g.profile_reset()
+    g.rehash(2 * g.capacity()); o.rehash(2 * o.capacity())
+    assert "k_rebuild_fused" in g.profile(), g.profile()
+    check_state(g, o, 0)
+    check_queries(g, o, np.concatenate([keys[:3000], keys[170_000:181_000]]))
+    # counting insert into the non-empty table (the oracle has no reducer: checked against numpy): values add up (std::plus)
+    g.profile_reset()
+    uk, cnt = np.unique(k2, return_counts=True)
+    before = dict(zip(*[x.tolist() for x in g.sorted_items()]))
+    assert g.insert_reduce_plus(dev(k2)) == 0
+    assert "k_insert_fused" in g.profile(), g.profile()
+    after = dict(zip(*[x.tolist() for x in g.sorted_items()]))
+    for k, c in zip(uk[:5000].tolist(), cnt[:5000].tolist()):
+        if k in before:
+            assert after[k] == (before[k] + c) & 0xFFFFFFFF
+    assert np.array_equal(g.export_info(), o.export_info()) and g.size() == o.size()        # same key set, same layout
+    g.close()
+
+
 def test_general_path_when_fused_build_is_disabled():
     """the same bulk builds through the general path (k_dedup / k_chunk_count / k_chunk_carry / k_chunk_place):
     a subset of this file re-run in a child process with KH_DISABLE_FUSED_BUILD=1"""
