@@ -1143,6 +1143,7 @@ struct KhFusedParams {
   // early give-up on duplicate-heavy batches: after 64 chunks the distinct/record ratio predicts the final size; if even
   // 1.15x of it fits the next smaller capacity the speculation is hopeless, the remaining workgroups return at once
   uint64_t n_total, half_max_load;
+  uint64_t base_size;                                    // SRC == 2: elements already in the table (all of them stay)
   unsigned long long* est;                               // [0] distinct so far << 32 | records so far (ONE word: the pair must be
                                                          //     read consistently), [1] abort
   uint32_t* flags;
@@ -1220,7 +1221,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   if (tid == 0) {
     s_chunk = blockIdx.x;
     s_max = 0;
-    s_abort = SRC == 0 ? (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    s_abort = SRC != 1 ? (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   }
   __syncthreads();
   // the source table of a streamed insert lives in simg[] until the records are staged: every byte of LDS counts here
@@ -1232,11 +1233,13 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   const uint64_t Sc = (uint64_t)c * KH_L;
   const unsigned long long VALID = 1ull << 63;
   uint32_t m, rep_mask;
+  uint32_t vote_old = 0, vote_rec = 0;      // early give-up vote: elements that were in the table, records of the batch
   // (record indices travel as 11-bit fields next to a 5-bit distance code, 0xFFFF = empty slot: index 2047 stays unused)
   if (SRC == 0) {
     const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
     const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
     m = V.m;
+    vote_rec = m;
     const bool aborted = s_abort != 0;
     if (m >= KH_DD_M || aborted) {     // does not fit the staging area / speculation given up: general path
       if (tid == 0) {
@@ -1259,8 +1262,13 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
     const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
     for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+    if (s_abort != 0) {                // speculation given up by the vote of the first chunks (flagged there)
+      if (tid == 0) __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     const uint32_t n_old = kh_stage_from_table<HASH, true>(P.R, c, Sc, lk, liv, &s_x);     // (ends with a barrier)
     m = n_old + V.m;
+    vote_old = n_old; vote_rec = V.m;
     if (n_old >= KH_DD_M || m >= KH_DD_M) {
       if (tid == 0) {
         atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
@@ -1346,12 +1354,12 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   }
   // ---- publish / look back
   if (tid == 0) {
-    if (SRC == 0 && c < 64) {     // the first 64 chunks vote on the duplicate ratio (same-address atomics are kept off the other 65 K)
-      const unsigned long long mine = ((unsigned long long)n_c << 32) | m;
+    if (SRC != 1 && c < 64) {     // the first 64 chunks vote on the duplicate ratio (same-address atomics are kept off the other 65 K)
+      const unsigned long long mine = ((unsigned long long)(n_c - vote_old) << 32) | vote_rec;     // new distinct keys, records
       const unsigned long long tot = atomicAdd(&P.est[0], mine) + mine;      // < 64 * 2048 records: the low word cannot carry
       const uint32_t sn = (uint32_t)(tot >> 32), sm = (uint32_t)tot;
       if ((c == 63 || (nch < 64 && c == nch - 1)) && sm > 0) {
-        const double dhat = (double)P.n_total * (double)sn / (double)sm * 1.15;
+        const double dhat = (double)P.base_size + (double)P.n_total * (double)sn / (double)sm * 1.15;
         if (dhat <= (double)P.half_max_load) {
           atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
           __hip_atomic_store(&P.est[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -604,6 +604,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);          // 2 x u64
     F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);                  // KH_NFLAGS x u32
     memset(&F.R, 0, sizeof(F.R));
+    F.base_size = 0;
     F.n_total = n;
     // giving up early only makes sense if a smaller capacity is possible at all (an insert never shrinks the table)
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
@@ -688,6 +689,9 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);
     F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);
     F.n_total = n;
+    F.base_size = t->lsize;
+    // giving up early only makes sense if the smaller capacity is possible at all (an insert never shrinks the table)
+    F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
     F.R.Old = t->cur; F.R.New = nw; F.R.PB = PB; F.R.seed = t->seed; F.R.flags = F.flags;
     { Launch L(t, "k_insert_fused");
       KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }

@@ -5,7 +5,11 @@ import numpy as np, torch
 import kmerhash_amd as kh
 from kmerhash_amd import workloads as W
 n = 100_000_000
-dk = torch.from_numpy(W.distinct_u64(n, seed=1).view(np.int64)).cuda(); dv = torch.arange(n, device="cuda", dtype=torch.int32)
+if len(sys.argv) > 1 and sys.argv[1] == "w1":            # x5.5 multiplicity: the capacity prediction fails, the early vote must catch it
+    kk, vv = W.w1_benchmark_hashtables(n, seed=23)
+    dk = torch.from_numpy(kk.view(np.int64)).cuda(); dv = torch.from_numpy(vv.view(np.int32)).cuda()
+else:
+    dk = torch.from_numpy(W.distinct_u64(n, seed=1).view(np.int64)).cuda(); dv = torch.arange(n, device="cuda", dtype=torch.int32)
 for rep in range(3):
     t = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
     torch.cuda.synchronize(); t0 = time.perf_counter()
