@@ -8,7 +8,9 @@
 // max(home, previous slot + 1)) by one workgroup that histograms the chunk's home buckets in LDS and
 // runs a max-plus scan over them; run-over between chunks is a (max,+) carry.  Bulk builds into an
 // empty table do all of that after the partition in ONE kernel (k_build_fused, one-deep carry
-// look-back); the general path is k_dedup -> k_chunk_count -> k_chunk_carry -> k_chunk_place.
+// look-back); the same kernel re-lays out a non-empty Robin Hood table from the table itself (SRC 1:
+// erase, rehash) and merges a batch into it (SRC 2: table elements + batch records folded in LDS).
+// The general path is k_dedup -> k_chunk_count -> k_chunk_carry -> k_chunk_place.
 // Read-only batches (find/count) and erase marking probe the table directly, one query per lane.
 //
 // Wave64 everywhere; no MFMA (integer/indexing path).
