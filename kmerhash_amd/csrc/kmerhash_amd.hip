@@ -316,9 +316,13 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
   // ---- one-launch rebuild (k_build_fused with the current table as its source): Robin Hood, same or doubled capacity.
   // Speculative like the bulk build: a chunk denser than the staging area, a carry chain or a poll time-out raise a flag,
   // and the three-kernel path below redoes the work into the same buffer.
-  if (t->kind == KHK_RH && t->lsize > 0 && !pre && !g_disable_fused_rebuild && t->cur.cap >= 2 * (uint64_t)KH_L &&
-      (new_cap == t->cur.cap || new_cap == 2 * t->cur.cap) && total_after <= threshold(new_cap, 0.9f) &&
-      (!noff || PB >= log2u(new_cap >> KH_LB))) {
+  // Also taken with an EMPTY source table (either kind): the batch was de-duplicated on the general path and only its
+  // distinct keys (ck/cv lists) have to be laid out.
+  const bool from_empty = t->lsize == 0;
+  if (!pre && !g_disable_fused_rebuild && new_cap >= 2 * (uint64_t)KH_L && total_after <= threshold(new_cap, 0.9f) &&
+      (!noff || PB >= log2u(new_cap >> KH_LB)) &&
+      (from_empty ? noff != nullptr
+                  : (t->kind == KHK_RH && t->cur.cap >= 2 * (uint64_t)KH_L && (new_cap == t->cur.cap || new_cap == 2 * t->cur.cap)))) {
     const size_t keep_blk = t->blk, keep_off = t->off;
     char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
     const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
@@ -337,9 +341,10 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
     F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);
     F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);
     F.R.Old = t->cur; F.R.erased_bits = erased; F.R.New = nw; F.R.ck = ck; F.R.cv = cv; F.R.noff = noff; F.R.ncnt = ncnt; F.R.PB = PB;
+    if (from_empty) F.R.Old.cap = 0;     // nothing to carry over: the source scan is skipped
     F.R.seed = t->seed; F.R.flags = F.flags;
     { Launch L(t, "k_rebuild_fused");
-      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     { Launch L(t, "k_fused_totals");
       hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
     { Launch L(t, "k_fused_tail");
@@ -351,7 +356,7 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
       T0.Old = KhSlots{nullptr, nullptr, nullptr, 0}; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0;
       T0.PB = log2u(new_cap >> KH_LB);       // the parked list is chunk 0's own: one partition per chunk
       T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
-      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_chunk_place<KHK_RH, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
+      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
