@@ -118,6 +118,20 @@ def cpu_baseline(keys, vals, q):
            "sample": "first %d inserts + %d finds of the same stream, oracle RH table (1 thread, g++ -O3)" % (n, nq),
            "inserts_per_s": n / ti, "finds_per_s": nq / tf}
     del t
+    # the REAL reference where it could be compiled (oracle/_ref: fsc::hashmap_linearprobe_doubling built from the reference
+    # tree as it lies; the Robin Hood header needs an absent kmerind header): same sample, same hash, one thread -- shows that
+    # the port's speed is representative of the reference's own tables
+    try:
+        if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_lp.so")):
+            r = O.RefLPTable(128, 0.35, 0.8, O.HASH_MURMUR3_X86, 43)
+            ri = r.timed_insert(keys[:n], vals[:n])
+            rc, rhits = r.timed_count(q[:nq])
+            assert rhits == nq
+            out["reference_lp"] = {"kind": "reference", "cores": 1, "inserts_per_s": n / ri, "counts_per_s": nq / rc,
+                                   "sample": "the same sample through the reference's own hashmap_linearprobe_doubling (insert + count)"}
+            del r
+    except Exception as e:
+        out["reference_lp"] = {"error": repr(e)}
     try:
         P = max(1, min(len(os.sched_getaffinity(0)), 16))       # the GPU box's CPU share for one GPU is 16 cores
         if P > 1:
