@@ -1758,3 +1758,104 @@ __global__ __launch_bounds__(256) void k_fastq_mask(const uint8_t* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small batches in place.  A handful of keys does not justify re-laying out a table of 10^8 elements (1.3 ms): one lane
+// applies them one after the other with the reference's own single-key algorithms -- Robin Hood insert with displacement
+// (hashmap_robinhood.hpp:522-624), backward-shift erase (:1294-1356), linear-probe insert into the first deleted slot of
+// the probe path or the first empty one (hashmap_linearprobe.hpp:430-513).  The host takes this path only when no call of
+// the batch can trigger a doubling (size + n <= max_load), so the serial semantics (first value wins, update overwrites,
+// std::plus adds) are exactly the reference's.  The Robin Hood info array stays canonical: it is the reference's own
+// algorithm.  A displacement chain that would push an element past distance 127 is detected by a read-only dry run of
+// the chain BEFORE the key is applied: the key and the rest of the batch are left to the general path (out[1] = keys done).
+// ---------------------------------------------------------------------------------------------
+enum { KH_SMALL_FIRST = 0, KH_SMALL_UPDATE = 1, KH_SMALL_PLUS = 2, KH_SMALL_ERASE = 3 };
+template <int KIND, int HASH>
+__global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_t kstride, const char* __restrict__ vbase, uint32_t vstride,
+                              uint32_t vconst, uint32_t n, int op, uint64_t seed, unsigned long long* __restrict__ out /* [0] new/erased, [1] keys done */,
+                              uint32_t* __restrict__ flags) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint64_t mask = T.cap - 1;
+  unsigned long long changed = 0;
+  uint32_t i = 0;
+  for (; i < n; ++i) {
+    const uint64_t key = *reinterpret_cast<const uint64_t*>(kbase + (uint64_t)i * kstride);
+    const uint32_t val = vbase ? *reinterpret_cast<const uint32_t*>(vbase + (uint64_t)i * vstride) : vconst;
+    uint64_t p = kh_hash64<HASH>(key, seed) & mask;
+    if (KIND == KHK_RH) {
+      // ---- find phase (shared by insert and erase)
+      uint32_t reprobe = 0x80u;
+      bool found = false;
+      for (;;) {
+        const uint32_t inf = T.info[p];
+        if (inf < reprobe) break;
+        if (inf == reprobe && T.keys[p] == key) { found = true; break; }
+        ++reprobe; p = (p + 1) & mask;
+        if (reprobe > 0xFFu) break;
+      }
+      if (op == KH_SMALL_ERASE) {
+        if (!found) continue;
+        uint64_t q = (p + 1) & mask;
+        while (T.info[q] > 0x80u) {                       // occupied, distance >= 1: moves one slot towards its home
+          T.keys[p] = T.keys[q]; T.vals[p] = T.vals[q]; T.info[p] = (uint8_t)(T.info[q] - 1u);
+          p = q; q = (q + 1) & mask;
+        }
+        T.info[p] = 0x00;
+        ++changed;
+        continue;
+      }
+      if (found) {
+        if (op == KH_SMALL_UPDATE) T.vals[p] = val;
+        else if (op == KH_SMALL_PLUS) T.vals[p] += val;
+        continue;
+      }
+      if (reprobe > 0xFFu) break;                         // would sit past distance 127: general path decides
+      // ---- dry run of the displacement chain from (p, reprobe): distances only, nothing is written
+      {
+        uint64_t pp = p; uint32_t r = reprobe; bool over = false;
+        for (;;) {
+          const uint32_t cur = T.info[pp];
+          if (cur == 0x00u) break;
+          if (cur < r) r = cur;                           // the resident is displaced and travels on with its own distance
+          ++r; pp = (pp + 1) & mask;
+          if (r > 0xFFu) { over = true; break; }
+        }
+        if (over) break;
+      }
+      // ---- insert with displacement
+      uint64_t ck = key; uint32_t cv = val; uint32_t r = reprobe;
+      for (;;) {
+        const uint32_t cur = T.info[p];
+        if (cur == 0x00u) { T.keys[p] = ck; T.vals[p] = cv; T.info[p] = (uint8_t)r; break; }
+        if (cur < r) {
+          const uint64_t tk = T.keys[p]; const uint32_t tv = T.vals[p];
+          T.keys[p] = ck; T.vals[p] = cv; T.info[p] = (uint8_t)r;
+          ck = tk; cv = tv; r = cur;
+        }
+        ++r; p = (p + 1) & mask;
+      }
+      ++changed;
+    } else {
+      // linear probing: the key, or the first deleted slot of its probe path, or the first empty slot
+      uint64_t ins = KH_NONE;
+      bool found = false;
+      for (uint64_t step = 0; step < T.cap; ++step) {
+        const uint32_t inf = T.info[p];
+        if (inf == 0x40u) { if (ins == KH_NONE) ins = p; break; }
+        if (inf >= 0x80u) { if (ins == KH_NONE) ins = p; }
+        else if (T.keys[p] == key) { found = true; break; }
+        p = (p + 1) & mask;
+      }
+      if (found) {
+        if (op == KH_SMALL_UPDATE) T.vals[p] = val;
+        else if (op == KH_SMALL_PLUS) T.vals[p] += val;
+        continue;
+      }
+      if (ins == KH_NONE) { atomicOr(&flags[KH_FLAG_INTERNAL], 1u); break; }     // full table: cannot happen below max_load
+      T.keys[ins] = key; T.vals[ins] = val; T.info[ins] = 0x00;
+      ++changed;
+    }
+  }
+  out[0] = changed;
+  out[1] = i;
+}
+

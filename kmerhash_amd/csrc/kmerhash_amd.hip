@@ -829,6 +829,29 @@ kh_status insert_device(kh_table* t, const char* kb, uint32_t kstride, const cha
   return st;
 }
 
+// A handful of keys applied in place by one lane (k_small_batch) instead of re-laying out the table.  *done = keys applied
+// (all of them unless a Robin Hood displacement chain would pass distance 127: the caller continues on the general path).
+#define KH_SMALL_N 16
+const bool g_disable_small = getenv("KH_DISABLE_SMALL_BATCH") != nullptr;      // test hook
+kh_status small_batch(kh_table* t, const char* kb, uint32_t kstride, const char* vb, uint32_t vstride, uint32_t vconst, uint32_t n, int op,
+                      uint64_t* changed, uint32_t* done) {
+  unsigned long long* out; uint32_t* flags;
+  TAKE(out, unsigned long long, 2); TAKE(flags, uint32_t, KH_NFLAGS);
+  HIPCHK(hipMemsetAsync(out, 0, 16, t->stream));
+  HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
+  { Launch L(t, "k_small_batch");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_small_batch<KIND, HASH>), dim3(1), dim3(64), 0, t->stream, t->cur, kb, kstride, vb, vstride,
+                                                             vconst, n, op, t->seed, out, flags)); }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(t->hpin, out, 16, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipMemcpyAsync(t->hpin + 2, flags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  if (reinterpret_cast<const uint32_t*>(t->hpin + 2)[KH_FLAG_INTERNAL]) return fail(t, KH_ERR_FULL, "ERROR: did not find a slot to insert into (hashmap_linearprobe.hpp:503)");
+  *changed = t->hpin[0];
+  *done = (uint32_t)t->hpin[1];
+  return KH_OK;
+}
+
 kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void* vals, uint32_t vstride, uint64_t n,
                     kh_mem where, int mode, uint64_t* n_inserted) {
   if (n_inserted) *n_inserted = 0;
@@ -859,7 +882,25 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
     }
   }
   uint64_t total_new = 0;
-  kh_status st = insert_device(t, kb, kstride, vb, vstride, n, mode, &total_new);
+  kh_status st = KH_OK;
+  // a handful of keys into a table with room for all of them (no insert() call of the batch can trigger the doubling):
+  // applied in place, one after the other, by the reference's own single-key algorithms
+  if (n > 0 && n <= KH_SMALL_N && t->lsize > 0 && t->lsize + n <= t->max_load && !g_disable_small) {
+    uint64_t ch = 0; uint32_t done = 0;
+    st = small_batch(t, kb, kstride, vb, vstride, mode == INS_PLUS ? 1u : 0u, (uint32_t)n,
+                     mode == INS_UPDATE ? KH_SMALL_UPDATE : (mode == INS_PLUS ? KH_SMALL_PLUS : KH_SMALL_FIRST), &ch, &done);
+    if (st != KH_OK) return st;
+    t->lsize += ch;
+    total_new = ch;
+    kb += (uint64_t)done * kstride;
+    if (vb) vb += (uint64_t)done * vstride;
+    n -= done;                      // > 0 only when a displacement chain would pass distance 127: the general path reports it
+  }
+  if (n > 0) {
+    uint64_t more = 0;
+    st = insert_device(t, kb, kstride, vb, vstride, n, mode, &more);
+    total_new += more;
+  }
   // trailing reserve(lsize) of insert(Iter,Iter) (:672 / :546): a no-op unless size > max_load (after set_max_load_factor).
   // kh_update stands for a sequence of update(k,v) calls (:1274), which has no such tail
   if (st == KH_OK && mode != INS_UPDATE) st = do_reserve(t, t->lsize);
@@ -953,6 +994,14 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
   const uint64_t* q;
   kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
   if (st != KH_OK) return st;
+  if (t->kind == KHK_RH && n <= KH_SMALL_N && t->lsize > 0 && !g_disable_small) {      // backward-shift deletes in place
+    uint64_t ne = 0; uint32_t done = 0;
+    st = small_batch(t, reinterpret_cast<const char*>(q), 8, nullptr, 0, 0, (uint32_t)n, KH_SMALL_ERASE, &ne, &done);
+    if (st != KH_OK) return st;
+    t->lsize -= ne;
+    *n_erased = ne;
+    return KH_OK;
+  }
   unsigned long long* cnt; uint32_t* bits = nullptr;
   TAKE(cnt, unsigned long long, 1);
   HIPCHK(hipMemsetAsync(cnt, 0, 8, t->stream));

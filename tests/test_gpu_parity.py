@@ -215,6 +215,78 @@ def test_probe_overflow_is_refused(oracle):
     g.close()
 
 
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_small_batches_are_applied_in_place(oracle, kname, cls, kind):
+    """a handful of keys (<= 16, no doubling possible) is applied by one lane with the reference's single-key algorithms
+    (k_small_batch) instead of a re-layout of the table: insert / update / std::plus / erase, duplicates inside the batch,
+    existing and new keys; state bit-exact after every call"""
+    keys = W.distinct_u64(300_000, seed=41)
+    vals = np.arange(len(keys), dtype=np.uint32)
+    g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    assert g.insert(dev(keys[:250_000]), dev(vals[:250_000])) == o.insert(keys[:250_000], vals[:250_000])
+    g.profile_enable(True)
+    rng = np.random.default_rng(8)
+    for step in range(60):
+        m = int(rng.integers(1, 17))
+        ks = np.concatenate([keys[rng.integers(0, 250_000, m // 2)], keys[250_000 + rng.integers(0, 50_000, m - m // 2)]])
+        ks = ks[rng.permutation(len(ks))]
+        if m > 3:
+            ks[1] = ks[0]                                            # a duplicate inside the batch
+        vs = rng.integers(0, 2**32, len(ks), dtype=np.uint32)
+        op = step % 4
+        if op == 0:
+            assert g.insert(dev(ks), dev(vs)) == o.insert(ks, vs), step
+        elif op == 1:
+            assert g.insert(ks, vs) == o.insert(ks, vs), step          # host buffers
+        elif op == 2:
+            g.update(ks, vs)
+            for k, v in zip(ks.tolist(), vs.tolist()):
+                o.update_one(k, v)
+        else:
+            if kind == 0:
+                assert g.erase(dev(ks)) == o.erase(ks), step
+            else:
+                assert g.erase(ks) == o.erase(ks), step
+        check_state(g, o, kind)
+    prof = g.profile()
+    assert "k_small_batch" in prof and "k_chunk_place" not in prof and "k_rebuild_fused" not in prof and "k_insert_fused" not in prof, prof
+    # std::plus on existing and new keys (numpy statement)
+    ks = np.concatenate([keys[:3], keys[:3], W.distinct_u64(2, seed=99)])
+    before = dict(zip(*[x.tolist() for x in g.sorted_items()]))
+    assert g.insert_reduce_plus(dev(ks)) == 2
+    after = dict(zip(*[x.tolist() for x in g.sorted_items()]))
+    for k in keys[:3].tolist():
+        assert after[k] == (before[k] + 2) & 0xFFFFFFFF
+    for k in W.distinct_u64(2, seed=99).tolist():
+        assert after[k] == 1
+    g.close()
+
+
+def test_small_batch_defers_probe_overflow_to_the_general_path(oracle):
+    """128 keys with one home bucket occupy distances 0..127; the 129th, inserted alone, would need distance 128: the dry run of
+    the in-place path sees it, the general path refuses, the table is unchanged"""
+    g = kh.hashmap_robinhood_doubling(1 << 14, 0.35, 0.8, hash="identity")
+    same_home = np.uint64(4000) + (np.arange(1, 130, dtype=np.uint64) << np.uint64(32))
+    assert g.insert(same_home[:100], np.arange(100, dtype=np.uint32)) == 100
+    for i in range(100, 128):                                          # single-key inserts: the in-place path
+        assert g.insert(same_home[i:i + 1], np.array([i], dtype=np.uint32)) == 1
+    assert int(np.flatnonzero(g.displacement_histogram())[-1]) == 127
+    with pytest.raises(kh.KhError) as ei:
+        g.insert(same_home[128:129], np.array([128], dtype=np.uint32))
+    assert "KH_ERR_PROBE_OVERFLOW" in str(ei.value)
+    assert g.size() == 128 and g.count(same_home[:128]).all() and not g.count(same_home[128:129]).any()
+    # a second element of the bucket in front of the pile displaces it by one slot: its last element would pass distance 127
+    front = np.uint64(3999) + (np.arange(1, 3, dtype=np.uint64) << np.uint64(32))
+    assert g.insert(front[:1], np.array([1], dtype=np.uint32)) == 1               # slot 3999 was free
+    with pytest.raises(kh.KhError):
+        g.insert(front[1:], np.array([2], dtype=np.uint32))
+    assert g.size() == 129 and g.count(same_home[:128]).all() and g.count(front).tolist() == [1, 0]
+    assert g.erase(front[:1]) == 1 and g.erase(same_home[5:6]) == 1               # backward shifts in place
+    assert g.insert(same_home[128:129], np.array([128], dtype=np.uint32)) == 1   # now there is room: distance 127 again
+    assert int(np.flatnonzero(g.displacement_histogram())[-1]) == 127 and g.size() == 128
+    g.close()
+
+
 def test_hash_batch_matches_oracle(oracle):
     keys = np.concatenate([np.arange(0, 1003, dtype=np.uint64), W.distinct_u64(10_000, seed=2),
                            np.array([0xFFFFFFFFFFFFFFFF, 1 << 63, 1], dtype=np.uint64)])
