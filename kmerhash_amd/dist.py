@@ -81,6 +81,7 @@ class ShardedTable:
         self.group = group
         self.p = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
+        self._comm = None      # side stream of the pipelined insert, created on first use
 
     @property
     def local(self):
@@ -150,7 +151,9 @@ class ShardedTable:
         total = sum(sum(row) for row in rc)
         self.local.insert_begin(total, reduce_plus=reduce_plus)
         cur = torch.cuda.current_stream(self.b.torch_device)
-        comm = torch.cuda.Stream(device=self.b.torch_device)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(device=self.b.torch_device)
+        comm = self._comm
         keep, landed = [], None
         for i in range(chunks):
             a, b = bounds[i], bounds[i + 1]
