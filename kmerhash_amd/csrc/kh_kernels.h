@@ -1162,9 +1162,12 @@ struct KhFusedParams {
 // MERGE (SRC == 2): the staged table elements will be folded together with the batch's records of this chunk, so they
 // carry iv = 0 << 32 | value (stream position field 0: an element of the table beats every record of the batch, whose
 // position fields are shifted up by one) and the new distinct lists are not read.
-template <int HASH, bool MERGE>
+// Linear probing (KIND == KHK_LP): the info byte carries no distance, so the home is hash & mask, and an element of old
+// chunk o can sit anywhere up to the first EMPTY slot behind the chunk (searched window by window through *scratch);
+// tombstones are dropped, as a rehash of the reference drops them.
+template <int KIND, int HASH, bool MERGE>
 __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R, uint32_t c, uint64_t Sc, unsigned long long* lk,
-                                                         unsigned long long* liv, uint32_t* n_staged) {
+                                                         unsigned long long* liv, uint32_t* n_staged, uint32_t* scratch) {
   const uint32_t tid = threadIdx.x;
   const uint64_t cap_o = R.Old.cap, mask_o = cap_o - 1, mask_n = R.New.cap - 1;
   if (tid == 0) *n_staged = 0;
@@ -1174,19 +1177,48 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
     const uint32_t o = c & (nch_o - 1);
     const bool same = R.New.cap == cap_o;
     const uint64_t S = (uint64_t)o * KH_L;
-    for (uint32_t t0 = 0; t0 < KH_L + 128u; t0 += KH_CHUNK_THREADS) {
-      const uint32_t t = t0 + tid;
+    uint64_t len = KH_L + 128u;                               // Robin Hood: probe distance <= 127
+    if (KIND == KHK_LP) {
+      const uint64_t beyond = cap_o - KH_L;
+      uint64_t e_total = beyond;
+      for (uint64_t base = 0; base < beyond; base += KH_L) {
+        const uint32_t window = beyond - base < KH_L ? (uint32_t)(beyond - base) : KH_L;
+        __syncthreads();
+        if (tid == 0) *scratch = window;
+        __syncthreads();
+        for (uint32_t t = tid; t < window; t += KH_CHUNK_THREADS) {
+          if (R.Old.info[(S + KH_L + base + t) & mask_o] == 0x40u) { atomicMin(scratch, t); break; }
+        }
+        __syncthreads();
+        const uint32_t e = *scratch;
+        e_total = base + e;
+        if (e < window) break;
+      }
+      __syncthreads();
+      if (tid == 0) *scratch = 0;
+      len = KH_L + e_total;
+    }
+    for (uint64_t t0 = 0; t0 < len; t0 += KH_CHUNK_THREADS) {
+      const uint64_t t = t0 + tid;
       bool take = false;
       uint64_t key = 0; uint32_t val = 0, hrel = 0;
-      if (t < KH_L + 128u) {
+      if (t < len) {
         const uint64_t sl = (S + t) & mask_o;
         const uint32_t inf = R.Old.info[sl];
-        if (inf >= 0x80u && !(R.erased_bits && ((R.erased_bits[sl >> 5] >> (sl & 31)) & 1u))) {
-          const uint64_t home_o = (sl - (inf & 0x7Fu)) & mask_o;
-          if ((uint32_t)(home_o >> KH_LB) == o) {
-            key = R.Old.keys[sl];
-            const uint64_t hn = same ? home_o : (kh_hash64<HASH>(key, R.seed) & mask_n);
-            if ((uint32_t)(hn >> KH_LB) == c) { take = true; val = R.Old.vals[sl]; hrel = (uint32_t)(hn - Sc); }
+        if (KIND == KHK_RH) {
+          if (inf >= 0x80u && !(R.erased_bits && ((R.erased_bits[sl >> 5] >> (sl & 31)) & 1u))) {
+            const uint64_t home_o = (sl - (inf & 0x7Fu)) & mask_o;
+            if ((uint32_t)(home_o >> KH_LB) == o) {
+              key = R.Old.keys[sl];
+              const uint64_t hn = same ? home_o : (kh_hash64<HASH>(key, R.seed) & mask_n);
+              if ((uint32_t)(hn >> KH_LB) == c) { take = true; val = R.Old.vals[sl]; hrel = (uint32_t)(hn - Sc); }
+            }
+          }
+        } else if (inf < 0x40u) {
+          key = R.Old.keys[sl];
+          const uint64_t h = kh_hash64<HASH>(key, R.seed);
+          if ((uint32_t)((h & mask_o) >> KH_LB) == o && (uint32_t)((h & mask_n) >> KH_LB) == c) {
+            take = true; val = R.Old.vals[sl]; hrel = (uint32_t)((h & mask_n) - Sc);
           }
         }
       }
@@ -1268,7 +1300,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       if (tid == 0) __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
-    const uint32_t n_old = kh_stage_from_table<HASH, true>(P.R, c, Sc, lk, liv, &s_x);     // (ends with a barrier)
+    const uint32_t n_old = kh_stage_from_table<KIND, HASH, true>(P.R, c, Sc, lk, liv, &s_x, &s_max);     // (ends with a barrier)
     m = n_old + V.m;
     vote_old = n_old; vote_rec = V.m;
     if (n_old >= KH_DD_M || m >= KH_DD_M) {
@@ -1288,7 +1320,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
     __syncthreads();
   } else {
-    m = kh_stage_from_table<HASH, false>(P.R, c, Sc, lk, liv, &s_x);
+    m = kh_stage_from_table<KIND, HASH, false>(P.R, c, Sc, lk, liv, &s_x, &s_max);
     if (m >= KH_DD_M) {                // denser than the staging area: general path
       if (tid == 0) {
         atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);

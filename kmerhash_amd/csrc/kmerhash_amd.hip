@@ -322,7 +322,7 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
   if (!pre && !g_disable_fused_rebuild && new_cap >= 2 * (uint64_t)KH_L && total_after <= threshold(new_cap, 0.9f) &&
       (!noff || PB >= log2u(new_cap >> KH_LB)) &&
       (from_empty ? noff != nullptr
-                  : (t->kind == KHK_RH && t->cur.cap >= 2 * (uint64_t)KH_L && (new_cap == t->cur.cap || new_cap == 2 * t->cur.cap)))) {
+                  : (t->cur.cap >= 2 * (uint64_t)KH_L && (new_cap == t->cur.cap || new_cap == 2 * t->cur.cap)))) {
     const size_t keep_blk = t->blk, keep_off = t->off;
     char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
     const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
@@ -668,7 +668,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   // next to the batch's records of the same chunk, folds them together (an element of the table beats every record), and
   // lays the chunk out -- no membership probes at random into HBM (k_dedup), no separate re-layout.  Speculates, like the
   // bulk build, that the capacity the reference's rule yields equals cap_u.
-  if (t->lsize > 0 && t->kind == KHK_RH && (mode == INS_FIRST || mode == INS_PLUS) && !forced_cap && !g_disable_fused_rebuild &&
+  if (t->lsize > 0 && (mode == INS_FIRST || mode == INS_PLUS) && !forced_cap && !g_disable_fused_rebuild &&
       t->cur.cap >= 2 * (uint64_t)KH_L && (cap_u == t->cur.cap || cap_u == 2 * t->cur.cap) && t->max_lf <= 0.9f &&
       PB == log2u(cap_u >> KH_LB) && t->lsize + n <= threshold(cap_u, 0.92f)) {
     const size_t keep_blk = t->blk, keep_off = t->off;
@@ -699,7 +699,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
     F.R.Old = t->cur; F.R.New = nw; F.R.PB = PB; F.R.seed = t->seed; F.R.flags = F.flags;
     { Launch L(t, "k_insert_fused");
-      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     { Launch L(t, "k_fused_totals");
       hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
     { Launch L(t, "k_fused_tail");
@@ -710,7 +710,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
       memset(&T0, 0, sizeof(T0));
       T0.Old = KhSlots{nullptr, nullptr, nullptr, 0}; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
       T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
-      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_chunk_place<KHK_RH, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
+      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));

@@ -11,7 +11,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "w1":            # x5.5 multiplicity: th
 else:
     dk = torch.from_numpy(W.distinct_u64(n, seed=1).view(np.int64)).cuda(); dv = torch.arange(n, device="cuda", dtype=torch.int32)
 for rep in range(3):
-    t = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    t = (kh.hashmap_linearprobe_doubling if "lp" in sys.argv else kh.hashmap_robinhood_doubling)(128, 0.35, 0.8)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     t.insert(dk[: n // 2], dv[: n // 2])
     torch.cuda.synchronize(); t1 = time.perf_counter()
