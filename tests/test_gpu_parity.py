@@ -482,6 +482,32 @@ def test_one_launch_relayouts_of_a_robin_hood_table(oracle, hname, hid):
     g.close()
 
 
+def test_one_launch_relayouts_of_a_linear_probe_table(oracle):
+    """the LP variants: second batch through k_insert_fused (tombstones of an earlier erase are dropped, the home comes from
+    the hash), doubling rehash through k_rebuild_fused; results (not layout) against the oracle"""
+    n = 380_000
+    keys = W.distinct_u64(n, seed=37)
+    vals = np.arange(n, dtype=np.uint32)
+    g = kh.hashmap_linearprobe_doubling(128, 0.35, 0.8); o = oracle.OracleTable(1, 128, 0.35, 0.8)
+    a = 200_000
+    assert g.insert(dev(keys[:a]), dev(vals[:a])) == o.insert(keys[:a], vals[:a])
+    assert g.erase(dev(keys[:30_000])) == o.erase(keys[:30_000])              # tombstones
+    k2 = np.concatenate([keys[a:], keys[20_000:40_000]])                         # new keys, erased keys coming back, keys of the table
+    k2 = k2[np.random.default_rng(5).permutation(len(k2))]
+    v2 = np.arange(len(k2), dtype=np.uint32) + np.uint32(5_000_000)
+    g.profile_enable(True)
+    assert g.insert(dev(k2), dev(v2)) == o.insert(k2, v2)
+    assert "k_insert_fused" in g.profile() and "k_dedup" not in g.profile(), g.profile()
+    check_state(g, o, 1)
+    assert int((g.export_info() == 0x80).sum()) == 0                             # the re-layout dropped the tombstones
+    g.profile_reset()
+    g.rehash(2 * g.capacity()); o.rehash(2 * o.capacity())
+    assert "k_rebuild_fused" in g.profile(), g.profile()
+    check_state(g, o, 1)
+    check_queries(g, o, np.concatenate([keys[:2000], keys[25_000:35_000], keys[-2000:]]))
+    g.close()
+
+
 def test_general_path_when_fused_build_is_disabled():
     """the same bulk builds through the general path (k_dedup / k_chunk_count / k_chunk_carry / k_chunk_place):
     a subset of this file re-run in a child process with KH_DISABLE_FUSED_BUILD=1"""
