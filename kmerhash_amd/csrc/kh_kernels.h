@@ -457,26 +457,45 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
 // global counter (exactly one lane observes the crossing), so no field can overflow whatever the key distribution.
 // The second-level histogram pass over the 16-byte records (0.32 ms at 1e8 keys) is not needed any more.
 #define KH_FULLHIST_THREADS 1024
+// More than 2^16 partitions (tables beyond 2^27 buckets): the partition ids are cut into 2^slice_bits slices of 2^16; one
+// launch per slice sweeps all keys and counts the ones whose id falls into its slice (two sweeps for 1.25e8 keys per GPU cost
+// 0.6 ms; the two-level fallback histogram costs 1.9 ms there).
 template <int HASH>
 __global__ __launch_bounds__(KH_FULLHIST_THREADS) void k_part_hist_full(const char* __restrict__ kbase, uint32_t kstride, uint64_t n, uint64_t seed,
-                                                                         uint32_t PB, uint32_t* __restrict__ counts /* [2^PB], zeroed */) {
-  extern __shared__ __align__(16) uint32_t kh_dyn_smem[];     // 2^PB / 2 words
-  const uint32_t words = PB ? (1u << (PB - 1)) : 1u;
+                                                                         uint32_t PB, uint32_t slice, uint32_t slice_bits,
+                                                                         uint32_t* __restrict__ counts /* [2^PB], zeroed */) {
+  extern __shared__ __align__(16) uint32_t kh_dyn_smem[];     // 2^(PB - slice_bits) / 2 words
+  const uint32_t lb = PB - slice_bits;                        // bits of the id inside a slice
+  const uint32_t words = lb ? (1u << (lb - 1)) : 1u;
+  const uint32_t lmask = (1u << lb) - 1u;
   for (uint32_t i = threadIdx.x; i < words; i += KH_FULLHIST_THREADS) kh_dyn_smem[i] = 0;
   __syncthreads();
   const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint64_t b0 = (uint64_t)blockIdx.x * per;
   const uint64_t b1 = b0 + per < n ? b0 + per : n;
-  for (uint64_t i = b0 + threadIdx.x; i < b1; i += KH_FULLHIST_THREADS) {
-    const uint64_t key = *reinterpret_cast<const uint64_t*>(kbase + i * kstride);
-    const uint32_t q = kh_part_q(kh_hash64<HASH>(key, seed), PB);
-    const uint32_t sh = 16u * (q & 1u);
-    const uint32_t old = atomicAdd(&kh_dyn_smem[q >> 1], 1u << sh);
-    if ((((old >> sh) & 0xFFFFu) + 1u) == 0x8000u) {
-      atomicSub(&kh_dyn_smem[q >> 1], 0x8000u << sh);
-      atomicAdd(&counts[q], 0x8000u);
+  // eight keys per lane and trip: their loads are in flight together (one dependent HBM round trip per trip, not per key)
+  for (uint64_t i0 = b0 + threadIdx.x; i0 < b1; i0 += 8 * KH_FULLHIST_THREADS) {
+    uint64_t key[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint64_t i = i0 + (uint64_t)j * KH_FULLHIST_THREADS;
+      key[j] = i < b1 ? *reinterpret_cast<const uint64_t*>(kbase + i * kstride) : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (i0 + (uint64_t)j * KH_FULLHIST_THREADS >= b1) break;
+      const uint32_t qg = kh_part_q(kh_hash64<HASH>(key[j], seed), PB);
+      if (slice_bits && (qg >> lb) != slice) continue;
+      const uint32_t q = qg & lmask;
+      const uint32_t sh = 16u * (q & 1u);
+      const uint32_t old = atomicAdd(&kh_dyn_smem[q >> 1], 1u << sh);
+      if ((((old >> sh) & 0xFFFFu) + 1u) == 0x8000u) {
+        atomicSub(&kh_dyn_smem[q >> 1], 0x8000u << sh);
+        atomicAdd(&counts[qg], 0x8000u);
+      }
     }
   }
+  counts += (size_t)slice << lb;
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < words; i += KH_FULLHIST_THREADS) {
     const uint32_t w = kh_dyn_smem[i];

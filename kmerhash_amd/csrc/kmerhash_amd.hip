@@ -483,19 +483,21 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     TAKE(counts2, uint32_t, nparts); TAKE(off2, uint64_t, nparts + 1); TAKE(cur2, unsigned long long, nparts);
     HIPCHK(hipMemsetAsync(counts2, 0, sizeof(uint32_t) * nparts, t->stream));
   }
-  const bool full_hist = B2 > 0 && PB <= 16;     // 2^16 16-bit bins = 128 KB of LDS
+  const bool full_hist = B2 > 0 && PB <= 18;     // 2^16 16-bit bins = 128 KB of LDS per sweep; up to four sweeps (slices of the id space)
   if (full_hist) {
     // one sweep over the keys gives the histogram of the full partition id; both levels' offsets follow from one scan
     int ncu = 256;
     hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, t->device);
     const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ncu, (n + 4095) / 4096));
+    const uint32_t slice_bits = PB > 16 ? PB - 16 : 0;
     { Launch L(t, "k_part_hist");
-      const size_t smem = (size_t)(nparts / 2) * 4;
+      const size_t smem = (size_t)((nparts >> slice_bits) / 2) * 4;
       KH_SWITCH_HASH(t->hash,
                      if (smem > 65536) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_part_hist_full<HASH>),
                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                     hipLaunchKernelGGL((k_part_hist_full<HASH>), dim3(grid), dim3(KH_FULLHIST_THREADS), smem, t->stream,
-                                        kbase, kstride, n, t->seed, PB, counts2)); }
+                     for (uint32_t sl = 0; sl < (1u << slice_bits); ++sl)
+                       hipLaunchKernelGGL((k_part_hist_full<HASH>), dim3(grid), dim3(KH_FULLHIST_THREADS), smem, t->stream,
+                                          kbase, kstride, n, t->seed, PB, sl, slice_bits, counts2)); }
     { Launch L(t, "k_scan");
       hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, counts2, (uint64_t)nparts, off2); }
     hipLaunchKernelGGL(k_seg_offsets, dim3((nb1 + 256) / 256), dim3(256), 0, t->stream, off2, nb1, nb2, off1, cur1);
