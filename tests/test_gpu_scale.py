@@ -62,6 +62,35 @@ def test_config1_full_size_rh_murmur():
     t.close()
 
 
+@pytest.mark.parametrize("cls", [kh.hashmap_robinhood_doubling, kh.hashmap_linearprobe_doubling])
+def test_config4_per_gpu_size_sliced_histogram(cls):
+    """configs[3] puts 1.25e8 keys on every GPU: capacity 2^28 = 2^17 chunks, more partitions than the single-sweep histogram
+    has bins (2^16), so the id space is swept in two slices; then a second batch into the non-empty table (merge kernel) and
+    an erase.  Size-independent checks, plus the Robin Hood invariants of the exported info array"""
+    n, n2, nq = 125_000_000, 20_000_000, 5_000_000
+    keys = W.distinct_u64(n + n2, seed=11)
+    dk = dev(keys)
+    dv = torch.arange(n + n2, dtype=torch.int32, device="cuda")
+    t = cls(128, 0.35, 0.8)
+    assert t.insert(dk[:n], dv[:n]) == n
+    assert t.size() == n and t.capacity() == 1 << 28
+    fk, fv = t.find(dk[:nq])
+    assert torch.equal(fk, dk[:nq]) and torch.equal(fv, dv[:nq])
+    assert int(t.count(dk[n:n + nq]).sum().item()) == 0
+    # second batch: 2e7 new keys + 1e6 repeats of keys of the table
+    k2 = torch.cat([dk[n:], dk[:1_000_000]]); v2 = torch.cat([dv[n:], dv[:1_000_000] + 7])
+    assert t.insert(k2, v2) == n2 and t.size() == n + n2 and t.capacity() == 1 << 28
+    fk, fv = t.find(dk[:nq])
+    assert torch.equal(fv, dv[:nq])                                  # first values kept
+    fk, fv = t.find(dk[n + n2 - nq:])
+    assert torch.equal(fk, dk[n + n2 - nq:]) and torch.equal(fv, dv[n + n2 - nq:])
+    assert t.erase(dk[100:100 + nq]) == nq and int(t.count(dk[100:100 + nq]).sum().item()) == 0
+    assert t.size() == n + n2 - nq
+    if cls is kh.hashmap_robinhood_doubling:
+        check_rh_info_invariants(t.export_info(), n + n2 - nq)
+    t.close()
+
+
 def test_exact_max_load_capacity_edge_full_size():
     """N' = 107374184 = size_t(float(2^27) * 0.8f): the table ends at load exactly 0.800 in 2^27 buckets only
     because the stream ends with the element that reaches max_load (SURVEY §7 capacity rule)"""
