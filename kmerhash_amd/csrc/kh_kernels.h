@@ -1304,7 +1304,19 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     }
     // ---- de-dup (as k_dedup, single round)
     for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
-    for (uint32_t i = tid; i < m; i += KH_CHUNK_THREADS) { const ulonglong2 rr = kh_src_load(V, s_ptr, s_cum, i); lk[i] = rr.x; liv[i] = rr.y; }
+    {   // all (<= 4) records of a lane are requested before the first one is stored: one HBM round trip, not four
+      ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+        const uint32_t i = it * KH_CHUNK_THREADS + tid;
+        if (i < m) rr[it] = kh_src_load(V, s_ptr, s_cum, i);
+      }
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+        const uint32_t i = it * KH_CHUNK_THREADS + tid;
+        if (i < m) { lk[i] = rr[it].x; liv[i] = rr[it].y; }
+      }
+    }
     if (V.n > 1) __syncthreads();       // the source table (in simg[]) has been read by every lane
     for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
     __syncthreads();
@@ -1329,9 +1341,18 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       }
       return;
     }
-    for (uint32_t i = tid; i < V.m; i += KH_CHUNK_THREADS) {
-      const ulonglong2 rr = kh_src_load(V, s_ptr, s_cum, i);
-      lk[n_old + i] = rr.x; liv[n_old + i] = rr.y + (1ull << 32);       // position + 1: 0 is "already in the table"
+    {   // (all of a lane's records requested before the first one is stored)
+      ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+        const uint32_t i = it * KH_CHUNK_THREADS + tid;
+        if (i < V.m) rr[it] = kh_src_load(V, s_ptr, s_cum, i);
+      }
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+        const uint32_t i = it * KH_CHUNK_THREADS + tid;
+        if (i < V.m) { lk[n_old + i] = rr[it].x; liv[n_old + i] = rr[it].y + (1ull << 32); }       // position + 1: 0 is "already in the table"
+      }
     }
     if (V.n > 1) __syncthreads();
     for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
