@@ -1217,6 +1217,46 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
       if (tid == 0) *scratch = 0;
       len = KH_L + e_total;
     }
+    if (KIND == KHK_RH) {
+      // the 2176 candidate slots are 4.25 per lane: all info bytes are requested at once, then all keys, then all values
+      // (three dependent HBM round trips per chunk instead of up to fifteen)
+      constexpr uint32_t NS = (KH_L + 128u + KH_CHUNK_THREADS - 1) / KH_CHUNK_THREADS;
+      uint32_t inf[NS], hrel[NS], valv[NS], cand = 0, takem = 0;
+      uint64_t keyv[NS];
+#pragma unroll
+      for (uint32_t it = 0; it < NS; ++it) {
+        const uint32_t t = it * KH_CHUNK_THREADS + tid;
+        inf[it] = t < KH_L + 128u ? R.Old.info[(S + t) & mask_o] : 0u;
+      }
+#pragma unroll
+      for (uint32_t it = 0; it < NS; ++it) {
+        const uint64_t sl = (S + it * KH_CHUNK_THREADS + tid) & mask_o;
+        keyv[it] = 0; hrel[it] = 0;
+        if (inf[it] >= 0x80u && !(R.erased_bits && ((R.erased_bits[sl >> 5] >> (sl & 31)) & 1u))) {
+          const uint64_t home_o = (sl - (inf[it] & 0x7Fu)) & mask_o;
+          if ((uint32_t)(home_o >> KH_LB) == o) { cand |= 1u << it; hrel[it] = (uint32_t)(home_o - S); keyv[it] = R.Old.keys[sl]; }
+        }
+      }
+#pragma unroll
+      for (uint32_t it = 0; it < NS; ++it) {
+        valv[it] = 0;
+        if ((cand >> it) & 1u) {
+          bool mine = true;
+          if (!same) {
+            const uint64_t hn = kh_hash64<HASH>(keyv[it], R.seed) & mask_n;
+            mine = (uint32_t)(hn >> KH_LB) == c;
+            hrel[it] = (uint32_t)(hn - Sc);
+          }
+          if (mine) { takem |= 1u << it; valv[it] = R.Old.vals[(S + it * KH_CHUNK_THREADS + tid) & mask_o]; }
+        }
+      }
+#pragma unroll
+      for (uint32_t it = 0; it < NS; ++it) {
+        const bool take = (takem >> it) & 1u;
+        const uint32_t x = kh_wave_append(take, n_staged);
+        if (take && x < KH_DD_M) { lk[x] = keyv[it]; liv[x] = MERGE ? (unsigned long long)valv[it] : (((unsigned long long)hrel[it] << 32) | valv[it]); }
+      }
+    } else
     for (uint64_t t0 = 0; t0 < len; t0 += KH_CHUNK_THREADS) {
       const uint64_t t = t0 + tid;
       bool take = false;
