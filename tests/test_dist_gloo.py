@@ -150,11 +150,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_table_world2_gloo(oracle):
+@pytest.mark.parametrize("world", [2, 3])      # 3: rank = hash % p (not a power of two), distributed_batched_robinhood_map.hpp:652
+def test_sharded_table_gloo(oracle, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
