@@ -1,5 +1,5 @@
 """CPU: the N>1 path (shard -> all_to_all counts -> all_to_allv payload -> local op -> results back with the
-swapped counts) on world_size 2 over gloo.  The device-specific pieces (local table, shard permute) are
+swapped counts) on world_size 2 and 3 over gloo.  The device-specific pieces (local table, shard permute) are
 supplied by an oracle-backed test backend; the exchange logic under test is kmerhash_amd.dist.ShardedTable,
 the same code the GPU ranks run over RCCL."""
 import os
