@@ -1,5 +1,6 @@
-"""soak: long differential fuzz of both tables against the CPU oracle (TEST INFRASTRUCTURE use of oracle/, like tests/).
-usage: python scripts/soak_fuzz.py [seconds] [first_seed]   -- prints the failing (seed, step, op) if anything differs"""
+"""soak: long differential fuzz of both tables against the CPU oracle (lives under tests/ because it uses oracle/; not collected by
+pytest: run it by hand on the GPU box).
+usage: python tests/soak_fuzz.py [seconds] [first_seed] [big] [one] [verbose]   -- prints the failing (seed, step, op) if anything differs"""
 import sys, time
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")

@@ -56,12 +56,13 @@ def test_unsupported_widths_are_refused(capi):
 
 
 def test_product_never_touches_the_oracle():
-    """oracle/ is test infrastructure: nothing under kmerhash_amd/ or include/ may import, link or call it"""
+    """oracle/ is test infrastructure: nothing under kmerhash_amd/, include/, benchmark/ or scripts/ may import, link or call it
+    (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do)"""
     bad = []
-    for base in ("kmerhash_amd", "include"):
+    for base in ("kmerhash_amd", "include", "benchmark", "scripts"):
         for dp, _, fns in os.walk(os.path.join(ROOT, base)):
             for fn in fns:
-                if fn.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
+                if fn.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".sh")):
                     txt = open(os.path.join(dp, fn), errors="ignore").read()
                     if re.search(r"oracle_py|kh_oracle|libkh_oracle|libref_lp|from oracle|import oracle", txt):
                         bad.append(os.path.join(dp, fn))

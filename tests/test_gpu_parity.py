@@ -606,7 +606,7 @@ def test_extreme_multiplicity_and_dense_chunks(oracle, kname, cls, kind):
 
 @pytest.mark.parametrize("kname,cls,kind", KINDS)
 def test_high_load_runs_longer_than_a_chunk(oracle, kname, cls, kind):
-    """found by scripts/soak_fuzz.py: at load 0.94 a 2^22-bucket table holds runs of occupied slots far longer than one
+    """found by tests/soak_fuzz.py: at load 0.94 a 2^22-bucket table holds runs of occupied slots far longer than one
     2048-slot chunk (probe distances stay small); re-laying out such a table (second insert, erase, rehash) must not depend
     on finding an empty slot within a chunk's length"""
     n = 3_940_000
@@ -635,7 +635,7 @@ def test_high_load_runs_longer_than_a_chunk(oracle, kname, cls, kind):
 
 @pytest.mark.parametrize("kname,cls,kind", KINDS)
 def test_update_has_no_trailing_reserve(oracle, kname, cls, kind):
-    """found by scripts/soak_fuzz.py: insert(Iter,Iter) ends with reserve(size) (hashmap_robinhood.hpp:672), which grows a table
+    """found by tests/soak_fuzz.py: insert(Iter,Iter) ends with reserve(size) (hashmap_robinhood.hpp:672), which grows a table
     whose max load factor was lowered below its load; update(k,v) (:1274) does not, so neither does a batch of updates --
     not even an empty one"""
     keys = W.distinct_u64(20_000, seed=5)
