@@ -2,24 +2,35 @@
 """bench.py -- the reference's headline benchmark on MI355X (BASELINE.json configs[1] at N=1).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Launch model.  Run plainly (no WORLD_SIZE in the environment) this process is the LAUNCHER: it never touches a GPU; it
+checks that N devices are visible (exit 2 otherwise -- never a silent fall-back to fewer ranks), runs the CPU baseline
+legs (N == 1 only), then starts N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 /
+MASTER_PORT set, one per device), relays rank 0's JSON line and propagates the first non-zero exit code.  Run under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE set) the process IS a rank and
+WORLD_SIZE must equal --gpus.  The reference's own multi-rank driver is started by mpirun and partitions by comm.size()
+(benchmark/BenchmarkDistHashTables.cpp:908-936, distributed_batched_robinhood_map.hpp:910-1194).
 
 A step = one pass of the hot path over one synthetic batch, inputs already resident in HBM:
     fresh table (capacity 128, min/max load 0.35/0.8, murmur3avx64 seed 43)
-    insert  KEYS_PER_GPU random DISTINCT 64-bit k-mers with 32-bit values (table doubles up to 2^27: load 0.745)
-    find    QUERIES_PER_GPU keys (all hits), compacted (key,value) result in query order
-This is the benchmark_hashmap phase sequence (BenchmarkHashTables.cpp:1037-1186) restricted to the two
-rates BASELINE.json's metric names.  N>1 (weak scaling): every rank generates its own KEYS_PER_GPU pairs,
-keys are sharded by murmur3(key, seed 9876543) & (N-1), exchanged with RCCL all_to_all_single, and inserted
-into the owner's local table; finds travel the same way and results return with the swapped counts.
+    insert  KEYS random DISTINCT 64-bit k-mers with 32-bit values; N == 1: KEYS = 107 374 184 = max_load(2^27, 0.8f), so the
+            table ends at capacity 2^27 and load exactly 0.800 (SURVEY 8d W2, N'); N > 1: 10^8 per rank (the shard a rank
+            receives is 10^8 +- ~10^4 keys, which must stay under max_load for every rank to do the same work: load 0.745)
+    find    QUERIES keys (all hits), compacted (key,value) result in query order
+This is the benchmark_hashmap phase sequence (BenchmarkHashTables.cpp:1037-1186) restricted to the two rates
+BASELINE.json's metric names.  N > 1 (weak scaling): every rank generates its own pairs, keys are sharded by
+murmur3(key, seed 9876543) & (N-1), exchanged over RCCL and inserted into the owner's local table (pipelined: exchange of
+piece i overlaps the radix partition of piece i-1); finds travel the same way and results return with the swapped counts.
 
-Rank 0 prints ONE JSON line: metric/value = whole-job k-mer operations (inserts + finds) per second, plus
-the two individual rates, the roofline of the dominant kernel (HIP-event timed inside the library on the
-table's stream) and a CPU baseline of the same workload on a bounded sample.
+Rank 0 prints ONE JSON line: metric/value = whole-job k-mer operations (inserts + finds) per second, the two individual
+rates, `roofline` (achieved = ops/s x algorithmic bytes/op; frac = the LOWER of the insert and find fractions of
+8 TB/s) and, at N == 1, `cpu_baseline` (the oracle port and the compiled reference LP table on a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,11 +40,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-KEYS_PER_GPU = 100_000_000
+KEYS_LOAD_080 = 107_374_184        # size_t(float(2^27) * 0.8f): hashmap_robinhood.hpp:263; load exactly 0.800
+KEYS_PER_GPU_DIST = 100_000_000
 QUERIES_PER_GPU = 10_000_000
-# algorithmic bytes per operation (AoS-equivalent sizes of the reference)
+# algorithmic bytes per operation (AoS-equivalent sizes of the reference) and the sector-granular figures
+# (every random touch moves >= 64 B): the realistic random-access bound
 B_INSERT_NEW, B_INSERT_DUP, B_FIND_HIT, B_FIND_MISS = 50, 33, 41, 9
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+B_INSERT_SECTOR, B_FIND_SECTOR = 16 + 3 * 64, 8 + 2 * 64 + 16
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 
 
 def gen_inputs(rank, n, nq, workload="w2"):
@@ -47,6 +61,9 @@ def gen_inputs(rank, n, nq, workload="w2"):
     return keys, vals, q
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (launcher process, N == 1 only; test infrastructure from oracle/ used as the thing timed BESIDE the product)
+# ---------------------------------------------------------------------------------------------------------------------
 def _cpu_shard_worker(path, start_at=0.0):
     """one 'rank' of the sharded CPU baseline: private oracle table over its share of the sample (own process, like the
     reference's MPI ranks: page faults of the doubling tables do not contend on one address space).  Prints one JSON line."""
@@ -64,7 +81,6 @@ def _cpu_shard_worker(path, start_at=0.0):
 
 def _cpu_sharded(keys, vals, q, P):
     import shutil
-    import subprocess
     import tempfile
     from oracle import oracle_py as O
     O.lib()                                    # compiled before the workers start
@@ -76,7 +92,6 @@ def _cpu_sharded(keys, vals, q, P):
         for i in range(P):
             path = os.path.join(tmp, "s%d.npz" % i)
             np.savez(path, k=keys[r == i], v=vals[r == i], q=q[rq == i])
-        # plain child processes (fresh interpreters), started before this process touches the GPU
         code = "import sys; sys.path.insert(0, %r); import bench; bench._cpu_shard_worker(sys.argv[1], float(sys.argv[2]))" % ROOT
         start_at = time.time() + 4.0
         for i in range(P):
@@ -104,9 +119,8 @@ def _cpu_sharded(keys, vals, q, P):
 def cpu_baseline(keys, vals, q):
     """the CPU oracle (own restatement of the reference RH table: kind 'port') timed on the host cores, on a bounded
     sample of the same stream.  value: ONE thread (the reference is single-threaded per rank: the benchmark_hashtables
-    number).  'sharded': the reference's MPI model without the communication: P threads, thread r owns
-    the keys with murmur3(key, seed 9876543) % P == r in a private table; aggregate rate over the slowest thread."""
-    import threading
+    number).  'sharded': the reference's MPI model without the communication: P processes, process r owns
+    the keys with murmur3(key, seed 9876543) % P == r in a private table; aggregate rate over the slowest process."""
     from oracle import oracle_py as O
     n = min(len(keys), 20_000_000)
     nq = min(len(q), 2_000_000)
@@ -142,53 +156,127 @@ def cpu_baseline(keys, vals, q):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--keys", type=int, default=KEYS_PER_GPU)
-    ap.add_argument("--queries", type=int, default=QUERIES_PER_GPU)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="w2", choices=["w2", "w1"],
-                    help="w2 = configs[1] (default, the metric's workload); w1 = benchmark_hashtables shape (x5.5 multiplicity), informational")
-    ap.add_argument("--hash", default="murmur3avx64", choices=["murmur3avx64", "murmur", "farm", "identity"],
-                    help="storage hash (default = the metric's: murmur3avx64; the others are informational)")
-    ap.add_argument("--chunks", type=int, default=0,
-                    help="N>1: pieces of the pipelined exchange/insert (permute, xGMI transfer and radix partition of successive pieces "
-                         "overlap); 1 = exchange, then one bulk insert; 0 = auto (4 when N>1: the exchange is link-bound at every N)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
+
+def child_env(rank, world, port, base=None):
+    """environment of rank `rank` of `world` (the torch.distributed.run contract: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)"""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "KH_BENCH_LAUNCHED": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def child_argv(argv):
+    """rank processes get the launcher's own arguments; the CPU legs stay with the launcher"""
+    out = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    if "--no-cpu-baseline" not in out:
+        out.append("--no-cpu-baseline")
+    return out
+
+
+def visible_gpus():
+    import torch                       # device_count() does not initialise the GPU
+    return torch.cuda.device_count()
+
+
+def launch(args, argv):
+    n = args.gpus
+    have = visible_gpus()
+    if have < n:
+        print("[bench] --gpus %d requested but only %d GPU(s) visible: refusing to run fewer ranks than asked for" % (n, have),
+              file=sys.stderr, flush=True)
+        return 2
+    cpu = None
+    if n == 1 and not args.no_cpu_baseline:
+        keys, vals, q = gen_inputs(0, args.keys, args.queries, args.workload)
+        cpu = cpu_baseline(keys, vals, q)
+        del keys, vals, q
+    port = _free_port()
+    cmd = child_argv(argv)
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen(cmd, env=child_env(r, n, port), stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                      universal_newlines=True))
+    out0 = None
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        for pr in procs:
+            pr.wait()
+            if pr.returncode != 0 and rc == 0:
+                rc = pr.returncode
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    if rc != 0:
+        print("[bench] a rank process failed (exit code %d)" % rc, file=sys.stderr, flush=True)
+        return rc
+    lines = [l for l in (out0 or "").splitlines() if l.strip().startswith("{")]
+    if not lines:
+        print("[bench] rank 0 printed no result line", file=sys.stderr, flush=True)
+        return 3
+    res = json.loads(lines[-1])
+    if cpu is not None:
+        res["cpu_baseline"] = cpu
+    print(json.dumps(res), flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
+def run_rank(args):
     # everything libraries write to stdout (RCCL prints a version banner there at communicator creation) goes to stderr,
     # so that stdout carries exactly ONE line: the JSON result
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ["WORLD_SIZE"])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or os.environ.get("KH_DIST_FORCE_COLLECTIVES", "0") == "1"   # rehearsal of the N>1 path on one GPU
+    if world != args.gpus:
+        print("[bench] WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr, flush=True)
+        return 2
+    force = os.environ.get("KH_DIST_FORCE_COLLECTIVES", "0") == "1"       # rehearsal of the N>1 code path on one GPU
+    distributed = world > 1 or force
     keys, vals, q = gen_inputs(rank, args.keys, args.queries, args.workload)
-    # CPU baseline first (rank 0, N=1 only): its worker processes are started before this process touches the GPU
-    cpu = cpu_baseline(keys, vals, q) if (not args.no_cpu_baseline and not distributed) else None
 
     import torch
     import kmerhash_amd as kh
     from kmerhash_amd import dist as khd
+    if torch.cuda.device_count() <= local_rank:
+        print("[bench] rank %d: device %d not visible" % (rank, local_rank), file=sys.stderr, flush=True)
+        return 2
     if args.chunks <= 0:
         args.chunks = 4 if world > 1 else 1
-    if distributed and "RANK" not in os.environ:
-        os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"})
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            print("[bench] process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus), file=sys.stderr, flush=True)
+            return 2
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)                       # every rank contributes a 1 over RCCL
+        rccl_ranks = int(one.item())
+        if rccl_ranks != args.gpus:
+            print("[bench] all-reduce over RCCL saw %d ranks, expected %d" % (rccl_ranks, args.gpus), file=sys.stderr, flush=True)
+            return 2
 
     n_distinct = len(np.unique(keys)) if args.workload == "w1" else args.keys
     dk = torch.from_numpy(keys.view(np.int64)).to(dev)
@@ -201,13 +289,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    prof = {}
+    prof, phases = {}, {}
     ins_ms, find_ms = [], []
 
     def one_step(timed):
         if distributed:
             be = khd.GpuBackend(local_rank, "rh", 128, 0.35, 0.8, args.hash, 43)
-            t = khd.ShardedTable(be)
+            t = khd.ShardedTable(be, timing=timed)
             table = be.table
         else:
             table = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=args.hash, seed=43, device=local_rank)
@@ -236,26 +324,14 @@ def main():
                 a = prof.setdefault(k, [0, 0.0])
                 a[0] += n
                 a[1] += ms
+            if t is not None:
+                for k, ms in t.timings().items():
+                    phases[k] = phases.get(k, 0.0) + ms
         state = (n_ins, n_hit, table.size(), table.capacity())
         table.close()
         return state
 
-    for w in range(args.warmup):
-        if distributed and w == 0 and args.chunks > 1:
-            # safety net for the pipelined exchange (it cannot be rehearsed with real peers on a one-GPU box): if any rank fails
-            # its first warm-up step, every rank falls back to exchange-then-insert for the rest of the run
-            ok = 1
-            try:
-                one_step(False)
-            except Exception as ex:           # noqa: BLE001
-                print("[bench] rank %d: pipelined insert failed (%r), falling back to --chunks 1" % (rank, ex), file=sys.stderr, flush=True)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                args.chunks = 1
-                one_step(False)
-            continue
+    for _ in range(args.warmup):       # a failure here (or anywhere) ends the rank with a non-zero exit code: no fall-back configuration
         one_step(False)
     barrier()
     t0 = time.perf_counter()
@@ -271,8 +347,12 @@ def main():
         tot = torch.tensor([state[0], state[1], state[2]], dtype=torch.int64, device=dev)
         dist.all_reduce(tot)
         g_ins, g_hit, g_size = (int(x) for x in tot.cpu())
+        im = torch.tensor([float(np.mean(ins_ms)), float(np.mean(find_ms))], dtype=torch.float64, device=dev)
+        dist.all_reduce(im, op=dist.ReduceOp.MAX)          # a phase ends when its slowest rank ends
+        ins_mean, find_mean = (float(x) for x in im.cpu())
     else:
         g_ins, g_hit, g_size = state[0], state[1], state[2]
+        ins_mean, find_mean = float(np.mean(ins_ms)), float(np.mean(find_ms))
 
     # size-independent parity properties at full size (the oracle cannot run 1e8 keys in seconds):
     # every distinct key inserted exactly once, every query found
@@ -286,28 +366,31 @@ def main():
     if rank == 0:
         ops_per_step = (args.keys + args.queries) * world
         ms_per_step = elapsed / args.steps * 1e3
-        ins_rate = args.keys * world / (np.mean(ins_ms) * 1e-3)
-        find_rate = args.queries * world / (np.mean(find_ms) * 1e-3)
-        # dominant kernel of the insert path, timed with HIP events inside the library on the table's stream
-        dom = max((k for k in prof if k.startswith("k_")), key=lambda k: prof[k][1] / max(prof[k][0], 1) * (prof[k][0] / args.steps))
+        ins_rate = args.keys * world / (ins_mean * 1e-3)
+        find_rate = args.queries * world / (find_mean * 1e-3)
+        # achieved = ops/s x algorithmic bytes per op (per GPU), over the driver-visible phase time
+        ins_gbs = ins_rate / world * B_INSERT_NEW / 1e9
+        find_gbs = find_rate / world * B_FIND_HIT / 1e9
+        low = "insert" if ins_gbs <= find_gbs else "find"
+        # the kernel with the largest time per step, HIP-event timed inside the library on the table's stream, and its HBM
+        # bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/<tag>_pmc_hbm_traffic.json,
+        # FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md prescribes; PMC counters cannot be read from
+        # inside the timed process, so this is the recorded figure).  hbm_util = measured traffic / time / peak: how busy the
+        # memory system is, NOT the 8d figure.
+        dom = max((k for k in prof if k.startswith("k_")), key=lambda k: prof[k][1])
         launches, total_ms = prof[dom]
         per_launch_ms = total_ms / launches
-        units = {"k_find": args.queries, "k_count": args.queries}.get(dom, args.keys)
-        bpu = {"k_find": B_FIND_HIT}.get(dom, B_INSERT_NEW)
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this same command
-        # (profiles/<tag>_pmc_hbm_traffic.json, FETCH_SIZE/WRITE_SIZE collected and corrected as MI355X_MICROARCH.md
-        # prescribes); PMC counters cannot be read from inside the timed process, so this is the recorded figure
-        traffic = None
+        traffic, traffic_src, path_traffic = None, None, None
         try:
             tag = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()      # written by scripts/summarize_profiles.py
-            traffic_src = "%s_pmc_hbm_traffic.json" % tag
             if not distributed:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", traffic_src))).get(dom, {}).get("hbm_bytes_per_launch")
+                pm = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.json" % tag)))
+                traffic = pm.get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_src = "%s_pmc_hbm_traffic.json" % tag
+                path_traffic = pm.get("_insert_path", {}).get("hbm_bytes_per_batch")
         except Exception:
             traffic = None
-        launches_per_step = launches / args.steps
-        alg_bytes = units * bpu / max(launches_per_step, 1.0)          # algorithmic bytes one launch accounts for
-        achieved = alg_bytes / (per_launch_ms * 1e-3) / 1e9
+        load = state[2] / state[3]
         out = {
             "metric": "kmer_inserts_plus_finds_per_sec",
             "value": ops_per_step / (elapsed / args.steps),
@@ -315,31 +398,72 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("(informational, benchmark_hashtables shape x5.5 multiplicity) " if args.workload == "w1" else "") + "configs[1]: Robin Hood table, %d distinct random 64-bit k-mers per GPU (max load 0.8 -> "
-                                   "capacity %d, load %.3f), murmur3avx64 seed 43, then %d all-hit finds per GPU%s"
-                                   % (args.keys, state[3], state[2] / state[3], args.queries,
-                                      "; keys sharded by murmur3(seed 9876543) over RCCL all_to_all" if distributed else ""),
+            "config": {"workload": ("(informational, benchmark_hashtables shape x5.5 multiplicity) " if args.workload == "w1" else "") +
+                                   "configs[1]: Robin Hood table, %d distinct random 64-bit k-mers per GPU (max load 0.8 -> capacity %d, "
+                                   "load %.3f), murmur3avx64 seed 43, then %d all-hit finds per GPU%s"
+                                   % (args.keys, state[3], load, args.queries,
+                                      "; keys sharded by murmur3(seed 9876543) over RCCL, exchange pipelined in %d pieces" % args.chunks if distributed else ""),
                        "keys_per_gpu": args.keys, "queries_per_gpu": args.queries, "table": "hashmap_robinhood_doubling",
-                       "hash": args.hash, "max_load_factor": 0.8, "min_load_factor": 0.35},
+                       "hash": args.hash, "max_load_factor": 0.8, "min_load_factor": 0.35, "final_load": load,
+                       "exchange_pieces": args.chunks if distributed else None},
+            "rccl_ranks": rccl_ranks,
             "inserts_per_s": ins_rate, "finds_per_s": find_rate,
-            "insert_ms": float(np.mean(ins_ms)), "find_ms": float(np.mean(find_ms)),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": (traffic_src if traffic else None),
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": per_launch_ms,
-                         "whole_insert_path_frac": ins_rate / world * B_INSERT_NEW / 1e9 / HBM_PEAK_GBS,
-                         "whole_find_path_frac": find_rate / world * B_FIND_HIT / 1e9 / HBM_PEAK_GBS},
+            "insert_ms": ins_mean, "find_ms": find_mean,
+            "roofline": {"bound": "hbm", "op": low, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "achieved": min(ins_gbs, find_gbs), "frac": min(ins_gbs, find_gbs) / HBM_PEAK_GBS,
+                         "formula": "ops/s per GPU x algorithmic bytes/op (SURVEY 8d: insert 50 B, find hit 41 B) / 8 TB/s; frac = the lower of the two ops",
+                         "insert": {"achieved": ins_gbs, "frac": ins_gbs / HBM_PEAK_GBS, "bytes_per_op": B_INSERT_NEW,
+                                    "sector_frac": ins_rate / world * B_INSERT_SECTOR / 1e9 / HBM_PEAK_GBS, "sector_bytes_per_op": B_INSERT_SECTOR,
+                                    "hbm_bytes_per_batch_pmc": path_traffic},
+                         "find": {"achieved": find_gbs, "frac": find_gbs / HBM_PEAK_GBS, "bytes_per_op": B_FIND_HIT,
+                                  "sector_frac": find_rate / world * B_FIND_SECTOR / 1e9 / HBM_PEAK_GBS, "sector_bytes_per_op": B_FIND_SECTOR},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "dominant_kernel": {"name": dom, "avg_launch_ms": per_launch_ms, "launches_per_step": launches / args.steps,
+                                             "hbm_bytes_per_launch_pmc": traffic,
+                                             "hbm_util": (traffic / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}},
             "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())},
         }
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
+        if distributed:
+            out["phases_ms_per_step_rank0"] = {k: round(v / args.steps, 4) for k, v in sorted(phases.items())}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if distributed:
         dist.destroy_process_group()
+    return 0
+
+
+def parse(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--keys", type=int, default=0, help="keys per GPU (0 = 107374184 at N=1: load exactly 0.800; 10^8 per rank at N>1)")
+    ap.add_argument("--queries", type=int, default=QUERIES_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="w2", choices=["w2", "w1"],
+                    help="w2 = configs[1] (default, the metric's workload); w1 = benchmark_hashtables shape (x5.5 multiplicity), informational")
+    ap.add_argument("--hash", default="murmur3avx64", choices=["murmur3avx64", "murmur", "farm", "identity"],
+                    help="storage hash (default = the metric's: murmur3avx64; the others are informational)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="N>1: pieces of the pipelined exchange/insert (permute, xGMI transfer and radix partition of successive pieces "
+                         "overlap); 1 = exchange, then one bulk insert; 0 = auto (4 when N>1: the exchange is link-bound at every N)")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.keys <= 0:
+        args.keys = KEYS_LOAD_080 if args.gpus == 1 else KEYS_PER_GPU_DIST
+    return args
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if "WORLD_SIZE" in os.environ:
+        return run_rank(args)
+    return launch(args, argv)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

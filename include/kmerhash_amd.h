@@ -81,6 +81,10 @@ kh_status kh_insert(kh_table* t, const void* keys /*[h|d] u64[n]*/, const void* 
                     uint64_t n, kh_mem where, uint64_t* n_inserted);
 /* same, input as the reference's std::pair<uint64_t,uint32_t> array (16 B: key @0, value @8) */
 kh_status kh_insert_pairs(kh_table* t, const void* pairs16 /*[h|d]*/, uint64_t n, kh_mem where, uint64_t* n_inserted);
+/* insert(value_type const&) / insert(key, val): the single-key form (hashmap_robinhood.hpp:522-626, hashmap_linearprobe.hpp:430-515).
+ *      Unlike the batch forms it is NOT followed by reserve(size()): the two differ after set_max_load_factor() lowered the
+ *      threshold below the current size. */
+kh_status kh_insert_one(kh_table* t, uint64_t key, uint32_t val, uint64_t* n_inserted /* 0 or 1 */);
 /* update(k,v) applied in order to a batch: insert, or overwrite the existing value (last one wins)
  *      hashmap_robinhood.hpp:1274-1284 / hashmap_linearprobe.hpp:895-905 */
 kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted);
@@ -90,8 +94,11 @@ kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n,
  *      block).  kh_insert_begin announces the exact total; every kh_insert_feed radix-partitions its piece at once and
  *      returns without synchronising (device pointers), so that work overlaps the next transfer; kh_insert_end de-duplicates
  *      and builds once.  The result equals kh_insert of the concatenated pieces in feed order (first value wins, same
- *      capacity rule).  reduce_plus != 0: kh_insert_reduce_plus semantics (vals may be NULL).  At most 16 feeds; no other
- *      mutating call on the table between begin and end. */
+ *      capacity rule).  reduce_plus != 0: kh_insert_reduce_plus semantics (vals may be NULL).  At most 16 feeds.  Between begin and
+ *      end every other call that mutates the table or uses its workspace (insert, update, erase, rehash, reserve, clear, find,
+ *      count, to_vector, displacement_histogram) returns KH_ERR_INVALID.  Host buffers (KH_MEM_HOST) may be reused as soon as
+ *      kh_insert_feed returns; device buffers must stay valid until the work queued on the table's stream has consumed them
+ *      (kh_insert_end synchronises). */
 kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus);
 kh_status kh_insert_feed(kh_table* t, const void* keys /*[h|d] u64[n]*/, const void* vals /*[h|d] u32[n]*/, uint64_t n, kh_mem where);
 kh_status kh_insert_end(kh_table* t, uint64_t* n_inserted);

@@ -355,7 +355,8 @@ class gpu_hashmap {
   std::pair<iterator, bool> insert(value_type const& v) {
     touch();
     uint64_t n = 0;
-    check(kh_insert_pairs(h_, &v, 1, KH_MEM_HOST, &n));
+    uint32_t vb; std::memcpy(&vb, &v.second, 4);
+    check(kh_insert_one(h_, key_bits(v.first), vb, &n));      // no trailing reserve(), unlike the batch forms (:522-624)
     return std::make_pair(find(v.first), n == 1);
   }
   std::pair<iterator, bool> insert(key_type const& key, mapped_type const& val) { return insert(value_type(key, val)); }

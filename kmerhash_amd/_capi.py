@@ -17,7 +17,7 @@ STATUS_NAMES = {0: "KH_OK", 1: "KH_ERR_INVALID", 2: "KH_ERR_NOMEM", 3: "KH_ERR_F
 SYMBOLS = [
     "kh_create", "kh_destroy", "kh_set_stream", "kh_last_error", "kh_size", "kh_capacity", "kh_get_load_thresholds",
     "kh_set_min_load_factor", "kh_set_max_load_factor", "kh_get_load_factors", "kh_clear", "kh_reserve", "kh_rehash",
-    "kh_insert", "kh_insert_pairs", "kh_update", "kh_insert_reduce_plus", "kh_insert_begin", "kh_insert_feed", "kh_insert_end", "kh_count", "kh_find", "kh_find_compact", "kh_find_compact_pairs",
+    "kh_insert", "kh_insert_pairs", "kh_insert_one", "kh_update", "kh_insert_reduce_plus", "kh_insert_begin", "kh_insert_feed", "kh_insert_end", "kh_count", "kh_find", "kh_find_compact", "kh_find_compact_pairs",
     "kh_erase", "kh_erase_one", "kh_to_vector", "kh_export_info", "kh_export_slots", "kh_displacement_histogram",
     "kh_hash_batch", "kh_shard_permute", "kh_profile_enable", "kh_profile_reset", "kh_profile_query", "kh_profile_dump",
     "kh_kmers_from_sequence", "kh_kmers_from_fastq", "kh_hll_create", "kh_hll_destroy", "kh_hll_set_stream", "kh_hll_update", "kh_hll_update_via_hashval",
@@ -64,6 +64,7 @@ def lib():
     L.kh_rehash.argtypes = [vp, u64]
     L.kh_insert.argtypes = [vp, vp, vp, u64, i32, pu64]
     L.kh_insert_pairs.argtypes = [vp, vp, u64, i32, pu64]
+    L.kh_insert_one.argtypes = [vp, u64, u32, pu64]
     L.kh_update.argtypes = [vp, vp, vp, u64, i32, pu64]
     L.kh_insert_reduce_plus.argtypes = [vp, vp, vp, u64, i32, pu64]
     L.kh_insert_begin.argtypes = [vp, u64, i32]

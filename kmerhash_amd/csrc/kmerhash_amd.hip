@@ -819,8 +819,12 @@ kh_status insert_device(kh_table* t, const char* kb, uint32_t kstride, const cha
     t->blk = keep_blk; t->off = keep_off;
     uint64_t nn = 0;
     if (take == 1 && t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) {
-      // single call: exactly one doubling, whatever the load afterwards
-      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, 1, mode, t->cur.cap << 1, &nn);
+      // single call: insert() runs rehash(2c) once (:530 / LP :439).  The LP rehash copies without looking at the load: exactly
+      // one doubling.  The RH rehash re-inserts through insert() (:432-464), whose own doubling check fires again while the copy
+      // is under way: the capacity ends where all lsize elements fit below max_load (the rule do_rehash applies)
+      uint64_t c = t->cur.cap << 1;
+      if (t->kind == KHK_RH) while (t->lsize > threshold(c, t->max_lf)) c <<= 1;
+      st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, 1, mode, c, &nn);
     } else {
       st = insert_core(t, kb + done * kstride, kstride, vb ? vb + done * vstride : nullptr, vstride, take, mode, 0, &nn);
     }
@@ -855,7 +859,7 @@ kh_status small_batch(kh_table* t, const char* kb, uint32_t kstride, const char*
 }
 
 kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void* vals, uint32_t vstride, uint64_t n,
-                    kh_mem where, int mode, uint64_t* n_inserted) {
+                    kh_mem where, int mode, uint64_t* n_inserted, bool tail_reserve = true) {
   if (n_inserted) *n_inserted = 0;
   if (n && !keys) return fail(t, KH_ERR_INVALID, "null keys");
   if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
@@ -905,7 +909,7 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
   }
   // trailing reserve(lsize) of insert(Iter,Iter) (:672 / :546): a no-op unless size > max_load (after set_max_load_factor).
   // kh_update stands for a sequence of update(k,v) calls (:1274), which has no such tail
-  if (st == KH_OK && mode != INS_UPDATE) st = do_reserve(t, t->lsize);
+  if (st == KH_OK && mode != INS_UPDATE && tail_reserve) st = do_reserve(t, t->lsize);
   if (st == KH_OK) HIPCHK(hipStreamSynchronize(t->stream));
   arena_consolidate(t);
   if (n_inserted) *n_inserted = total_new;
@@ -938,6 +942,7 @@ kh_status compact(kh_table* t, const uint8_t* flags, const uint64_t* q, const ui
 kh_status do_find(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint32_t* out_vals, uint8_t* out_found,
                   uint64_t* out_ckeys, uint32_t* out_cvals, void* out_pairs, bool compacted, uint64_t* n_found) {
   if (n_found) *n_found = 0;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   if (n == 0) return KH_OK;
   if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
@@ -1114,6 +1119,7 @@ kh_status kh_get_load_factors(const kh_table* t, float* mn, float* mx, float* cu
 }
 kh_status kh_clear(kh_table* t) {
   if (!t) return KH_ERR_INVALID;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
   t->lsize = 0;
   HIPCHK(hipMemsetAsync(t->cur.info, empty_byte(t->kind), t->cur.cap + 256, t->stream));
@@ -1130,6 +1136,10 @@ kh_status kh_insert(kh_table* t, const void* keys, const void* vals, uint64_t n,
 kh_status kh_insert_pairs(kh_table* t, const void* pairs16, uint64_t n, kh_mem where, uint64_t* n_inserted) {
   if (!t) return KH_ERR_INVALID;
   return do_insert(t, pairs16, 16, pairs16 ? static_cast<const char*>(pairs16) + 8 : nullptr, 16, n, where, INS_FIRST, n_inserted);
+}
+kh_status kh_insert_one(kh_table* t, uint64_t key, uint32_t val, uint64_t* n_inserted) {
+  if (!t) return KH_ERR_INVALID;
+  return do_insert(t, &key, 8, &val, 4, 1, KH_MEM_HOST, INS_FIRST, n_inserted, false);
 }
 kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted) {
   if (!t) return KH_ERR_INVALID;
@@ -1185,6 +1195,7 @@ kh_status kh_insert_feed(kh_table* t, const void* keys, const void* vals, uint64
     t->ins.S.rec[t->ins.S.n] = R.rec; t->ins.S.off[t->ins.S.n] = R.part_off; ++t->ins.S.n;
   }
   t->ins.fed += n;
+  if (where == KH_MEM_HOST) HIPCHK(hipStreamSynchronize(t->stream));   // host buffers may be reused as soon as the feed returns
   return KH_OK;
 }
 
@@ -1227,6 +1238,7 @@ kh_status kh_insert_reduce_plus(kh_table* t, const void* keys, const void* vals,
 
 kh_status kh_count(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint8_t* out01) {
   if (!t) return KH_ERR_INVALID;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   if (n == 0) return KH_OK;
   if (!keys || !out01) return fail(t, KH_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(t->device));
@@ -1287,6 +1299,7 @@ kh_status kh_erase_one(kh_table* t, uint64_t key, uint64_t* n_erased) {
 
 kh_status kh_to_vector(kh_table* t, uint64_t* keys_host, uint32_t* vals_host, uint64_t* n_out) {
   if (!t) return KH_ERR_INVALID;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
   { kh_status ps = arena_prepare(t, t->cur.cap * 14 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
   const uint64_t cap = t->cur.cap;
@@ -1324,6 +1337,7 @@ kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]) {
   if (!t || !out) return KH_ERR_INVALID;
   for (int i = 0; i < 128; ++i) out[i] = 0;
   if (t->kind != KHK_RH) return KH_OK;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
   { kh_status ps = arena_prepare(t, size_t(1) << 20); if (ps != KH_OK) return ps; }
   unsigned long long* d;

@@ -180,6 +180,12 @@ class _HashMapBase:
         self._chk(self._L.kh_insert(self._h, kb.ptr, vb.ptr, kb.n, kb.where, C.byref(out)))
         return out.value
 
+    def insert_one(self, key, val):
+        """insert(value_type const&): the single-key form -- no trailing reserve(size()) (hashmap_robinhood.hpp:522-626)."""
+        out = C.c_uint64()
+        self._chk(self._L.kh_insert_one(self._h, int(key), int(val), C.byref(out)))
+        return out.value
+
     def update(self, keys, vals):
         """update(k,v) applied in batch order: insert, or overwrite with the last value given."""
         kb, vb = _Buf(keys, np.uint64, 8), _Buf(vals, np.uint32, 4)

@@ -5,6 +5,9 @@
 TAG=${1:-r1}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
+# bench.py run as ONE rank directly (WORLD_SIZE set): under rocprofv3 the launcher form would start its rank as a child of a
+# process whose GPU the profiler has already initialised, which the box forbids
+export WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1 && \

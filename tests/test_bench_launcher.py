@@ -1,0 +1,48 @@
+"""CPU: bench.py's launcher plumbing: `--gpus N` starts N rank processes itself, refuses loudly when fewer
+devices are visible, and a rank refuses a WORLD_SIZE that differs from --gpus.  No GPU is touched here."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_defaults_follow_the_metric():
+    a = bench.parse([])
+    assert (a.gpus, a.keys, a.queries) == (1, 107_374_184, 10_000_000)       # load exactly 0.800 at capacity 2^27
+    assert bench.KEYS_LOAD_080 == int(__import__("numpy").float32(2 ** 27) * __import__("numpy").float32(0.8))
+    b = bench.parse(["--gpus", "8"])
+    assert (b.gpus, b.keys) == (8, 100_000_000)
+    assert bench.parse(["--gpus", "2", "--keys", "1000"]).keys == 1000
+
+
+def test_child_env_and_argv():
+    e = bench.child_env(3, 8, 29511, base={"PATH": "/bin", "WORLD_SIZE": "1"})
+    assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "29511")
+    assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/bin"
+    argv = bench.child_argv(["--gpus", "8", "--steps", "2"])
+    assert argv[0] == sys.executable and argv[1].endswith("bench.py")
+    assert argv[2:] == ["--gpus", "8", "--steps", "2", "--no-cpu-baseline"]
+    assert bench.child_argv(["--no-cpu-baseline"]).count("--no-cpu-baseline") == 1
+
+
+def _run(args, env_extra=None, drop=()):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK") + tuple(drop)}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          universal_newlines=True, timeout=300)
+
+
+def test_more_gpus_than_visible_fails_loudly():
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = _run(["--gpus", str(n), "--no-cpu-baseline", "--keys", "1000", "--queries", "10"])
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "refusing to run fewer ranks" in r.stderr and r.stdout.strip() == ""
+
+
+def test_rank_refuses_world_size_mismatch():
+    r = _run(["--gpus", "4", "--no-cpu-baseline"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 4" in r.stderr and r.stdout.strip() == ""

@@ -45,6 +45,20 @@ class OracleBackend:
                         new += s.t.insert(np.array([key], dtype=np.uint64), np.array([c], dtype=np.uint32))
                 return new
 
+            # streamed insert (kh_insert_begin / feed / end): ONE insert of the concatenated pieces, in feed order
+            def insert_begin(s, n_total, reduce_plus=False):
+                s._feed, s._total, s._plus = [], n_total, reduce_plus
+
+            def insert_feed(s, k, v=None):
+                s._feed.append((k.clone(), v.clone() if v is not None else None))
+
+            def insert_end(s):
+                k = torch.cat([a for a, _ in s._feed])
+                assert k.numel() == s._total
+                if s._plus:
+                    return s.insert_reduce_plus(k)
+                return s.insert(k, torch.cat([b for _, b in s._feed]))
+
             def count(s, k):
                 return torch.from_numpy(s.t.count(k.numpy().view(np.uint64)))
 
@@ -68,6 +82,9 @@ class OracleBackend:
         ok = torch.from_numpy(k[order].view(np.int64).copy())
         ov = torch.from_numpy(vals.numpy()[order].copy()) if vals is not None else None
         return ok, ov, counts
+
+    def shard_counts(self, keys, p):
+        return self.shard(keys, None, p)[2]
 
     def empty(self, n, dtype):
         return torch.empty(n, dtype=dtype)
@@ -93,6 +110,7 @@ def _worker(rank, world, port, q):
         tk = torch.from_numpy(keys.view(np.int64).copy())
         tv = torch.from_numpy(vals.view(np.int32).copy())
         st.insert(tk, tv)
+        assert st.collectives == {"counts": 1, "payload": 1}, st.collectives       # keys and values travel in ONE grouped exchange
         # single-table model: receive order is (source rank 0..p-1, then position)
         allk = [None] * world
         allv = [None] * world
@@ -112,11 +130,15 @@ def _worker(rank, world, port, q):
         assert gsize == len(np.unique(np.concatenate(allk)))
         # queries: results come back aligned with the permuted keys
         qk = np.concatenate([keys[:5000], W.distinct_u64(5000, seed=55 + rank)])
+        c0 = dict(st.collectives)
         pk, cnt = st.count(torch.from_numpy(qk.view(np.int64).copy()))
+        assert st.collectives == {"counts": c0["counts"] + 1, "payload": c0["payload"] + 2}
         universe = set(np.concatenate(allk).tolist())
         exp = np.array([1 if int(k) in universe else 0 for k in pk.numpy().view(np.uint64)], dtype=np.uint8)
         assert np.array_equal(cnt.numpy(), exp)
+        c0 = dict(st.collectives)
         pk2, fv, ff = st.find(torch.from_numpy(qk.view(np.int64).copy()))
+        assert st.collectives == {"counts": c0["counts"] + 1, "payload": c0["payload"] + 2}, st.collectives   # keys out, (values, flags) back
         assert np.array_equal(ff.numpy(), exp)
         # first-wins across ranks: the value of a duplicated key is the one from the lowest source rank
         first = {}
@@ -127,6 +149,25 @@ def _worker(rank, world, port, q):
         got = fv.numpy().view(np.uint32)
         for i in np.nonzero(exp)[0][:2000]:
             assert got[i] == first[int(pkk[i])]
+        # pipelined insert (khmxx::ialltoallv_and_modify analogue): 3 pieces, all counts in ONE exchange, one payload exchange per
+        # piece; the result equals one insert of the pieces concatenated piece-major (piece, source rank, position)
+        chunks = 3
+        sp = ShardedTable(OracleBackend(O, O.KIND_RH), timing=True)
+        sp.insert(tk, tv, chunks=chunks)
+        assert sp.collectives == {"counts": 1, "payload": chunks}, sp.collectives
+        assert set(sp.timings()) >= {"count_pass", "permute", "exchange", "feed", "build"}
+        bnd = [n * i // chunks for i in range(chunks + 1)]
+        model_p = O.OracleTable(O.KIND_RH, 128, 0.35, 0.8, O.HASH_MURMUR3_X86, 43)
+        for i in range(chunks):
+            for r in range(world):
+                kk, vv = allk[r][bnd[i]:bnd[i + 1]], allv[r][bnd[i]:bnd[i + 1]]
+                m = owner(kk) == rank
+                model_p.insert(kk[m], vv[m])
+        lp = sp.local.t
+        assert (lp.size(), lp.capacity()) == (model_p.size(), model_p.capacity())
+        assert np.array_equal(lp.export_info(), model_p.export_info())
+        a, b = lp.sorted_items(), model_p.sorted_items()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
         # counting insert (Reducer = std::plus): global multiplicities, each k-mer on its owner rank
         sc = ShardedTable(OracleBackend(O, O.KIND_RH))
         sc.insert_counts(tk)

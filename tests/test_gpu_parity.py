@@ -751,3 +751,75 @@ def test_streamed_insert_misuse_is_refused():
     g.insert_begin(100); g.insert_feed(k, v)
     assert g.insert_end() == 100 and g.count(k).all()
     g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+@pytest.mark.parametrize("form", ["update_one", "insert_one", "batch"])
+def test_more_than_one_doubling_pending(oracle, kname, cls, kind, form):
+    """after set_max_load_factor() lowered the threshold so far that size > max_load(2 * capacity), ONE insert call
+    re-doubles inside the Robin Hood rehash (copy() re-inserts through insert(), hashmap_robinhood.hpp:432-464,530): 20000
+    keys at capacity 32768 with max load 0.25 end at 131072, not 65536.  The LP rehash copies without the check: one doubling
+    per call.  The single-key insert(value_type) has no trailing reserve(size()), the batch forms do."""
+    keys = W.distinct_u64(20_001, seed=5)
+    vals = np.arange(len(keys), dtype=np.uint32)
+    g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    assert g.insert(dev(keys[:20_000]), dev(vals[:20_000])) == o.insert(keys[:20_000], vals[:20_000])
+    assert g.capacity() == 32768
+    g.set_max_load_factor(0.25); o.set_max_load_factor(0.25)         # max_load(65536) = 16384 < 20000
+    check_state(g, o, kind)
+    new_k, new_v = int(keys[20_000]), int(vals[20_000])
+    if form == "update_one":
+        g.update(np.array([keys[5]], dtype=np.uint64), np.array([77], dtype=np.uint32)); o.update_one(int(keys[5]), 77)
+    elif form == "insert_one":
+        assert g.insert_one(new_k, new_v) == o.insert_one(new_k, new_v) == 1
+    else:
+        b = np.concatenate([keys[:3], keys[20_000:]]); bv = np.concatenate([vals[:3] + 9, vals[20_000:]])
+        assert g.insert(dev(b), dev(bv)) == o.insert(b, bv) == 1
+    if kind == 0:
+        assert o.capacity() == 131072
+    check_state(g, o, kind)
+    # a second single-key insert of an existing key: an insert call like any other
+    assert g.insert_one(int(keys[7]), 1) == o.insert_one(int(keys[7]), 1) == 0
+    check_state(g, o, kind)
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_single_key_insert_has_no_trailing_reserve(oracle, kname, cls, kind):
+    """size == max_load(2 * capacity) exactly: insert(value_type) doubles once and leaves size = max_load + 1 in place; the batch
+    form of the same key ends with reserve(size()) and doubles again (hashmap_robinhood.hpp:522-624 vs :633-673)"""
+    for batch in (False, True):
+        g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+        keys = W.distinct_u64(16_385, seed=11)
+        vals = np.arange(len(keys), dtype=np.uint32)
+        assert g.insert(keys[:16_384], vals[:16_384]) == o.insert(keys[:16_384], vals[:16_384])
+        assert g.capacity() == 32768
+        g.set_max_load_factor(0.25); o.set_max_load_factor(0.25)     # max_load(65536) = 16384 == size
+        k, v = keys[16_384:], vals[16_384:]
+        if batch:
+            assert g.insert(k, v) == o.insert(k, v) == 1
+        else:
+            assert g.insert_one(int(k[0]), int(v[0])) == o.insert_one(int(k[0]), int(v[0])) == 1
+        check_state(g, o, kind)
+        g.close()
+
+
+def test_calls_inside_a_streamed_insert_are_refused():
+    """every entry point that resets the workspace arena refuses to run between kh_insert_begin and kh_insert_end
+    (the streamed insert keeps its partition buffers there)"""
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    k = W.distinct_u64(5000, seed=1)
+    v = np.arange(5000, dtype=np.uint32)
+    g.insert(k[:1000], v[:1000])
+    g.insert_begin(4000)
+    g.insert_feed(dev(k[1000:3000]), dev(v[1000:3000]))
+    for call in (lambda: g.find(k[:10]), lambda: g.find_values(k[:10]), lambda: g.count(k[:10]), g.to_vector, g.clear,
+                 g.displacement_histogram, lambda: g.erase(k[:10]), lambda: g.rehash(1 << 16), lambda: g.update(k[:1], v[:1])):
+        with pytest.raises(kh.KhError):
+            call()
+    g.insert_feed(k[3000:], v[3000:])
+    assert g.insert_end() == 4000 and g.size() == 5000
+    kk, vv = g.sorted_items()
+    o = np.argsort(k)
+    assert np.array_equal(kk, k[o]) and np.array_equal(vv, v[o])
+    g.close()
