@@ -38,35 +38,50 @@ enum { KH_FLAG_PROBE_OVERFLOW = 0, KH_FLAG_REGION_OVERFLOW = 1, KH_FLAG_COUNT_OV
 template <int KIND> __device__ __forceinline__ bool kh_is_empty(uint32_t b) { return KIND == KHK_RH ? (b == 0x00u) : (b == 0x40u); }
 template <int KIND> __device__ __forceinline__ bool kh_is_occupied(uint32_t b) { return KIND == KHK_RH ? (b >= 0x80u) : (b < 0x40u); }
 
+// One bucket of the table: 16 bytes, naturally aligned, read and written with ONE dwordx4 access.  A probe needs the info byte,
+// the key and (on a hit) the value of the same bucket: co-locating them makes a find touch one 64-byte sector of HBM where
+// the SoA layout of round 1 touched three (info / keys / values arrays: 3.9 memory requests per query measured).
+//   info: low byte = the reference's info_type byte (RH: 0x00 empty, 0x80|distance; LP: 0x40 empty, 0x80 deleted, 0x00 normal);
+//         bit 8 (KH_INFO_ERASE_MARK) = "dropped by the re-layout that follows" (Robin Hood batch erase), invisible to probes;
+//         the other bits are zero.
+struct __align__(16) KhSlot { uint64_t key; uint32_t val; uint32_t info; };
+#define KH_INFO_ERASE_MARK 0x100u
 struct KhSlots {
-  uint64_t* keys;
-  uint32_t* vals;
-  uint8_t* info;
+  KhSlot* s;
   uint64_t cap;   // power of two
 };
+__device__ __forceinline__ uint4 kh_slot_ld(const KhSlot* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void kh_slot_st(KhSlot* p, uint64_t key, uint32_t val, uint32_t info) {
+  uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = val; w.w = info;
+  *reinterpret_cast<uint4*>(p) = w;
+}
+__device__ __forceinline__ uint64_t kh_slot_key(const uint4& w) { return (uint64_t)w.x | ((uint64_t)w.y << 32); }
+template <int KIND> __device__ __forceinline__ uint32_t kh_empty_info() { return KIND == KHK_RH ? 0x00u : 0x40u; }
 
 // ---------------------------------------------------------------------------------------------
 // direct probing (find_pos): hashmap_robinhood.hpp:1058-1095 / hashmap_linearprobe.hpp:693-748
+// Every step is one 16-byte load; consecutive buckets share a 64-byte sector three times out of four.
 // ---------------------------------------------------------------------------------------------
 template <int KIND>
-__device__ __forceinline__ uint64_t kh_find_pos(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ info,
-                                                uint64_t mask, uint64_t home, uint64_t key) {
+__device__ __forceinline__ uint64_t kh_find_pos(const KhSlot* __restrict__ slots, uint64_t mask, uint64_t home, uint64_t key, uint32_t* val_out = nullptr) {
   uint64_t i = home;
   if (KIND == KHK_RH) {
     // reprobe = 0x80 + distance; stop as soon as the resident entry is "richer" (or the slot is empty).
     for (uint32_t reprobe = 0x80u; reprobe < 0x100u; ++reprobe) {
-      uint32_t b = info[i];
+      const uint4 w = kh_slot_ld(slots + i);
+      const uint32_t b = w.w & 0xFFu;
       if (reprobe > b) return KH_NONE;
-      if (reprobe == b && keys[i] == key) return i;
+      if (reprobe == b && kh_slot_key(w) == key) { if (val_out) *val_out = w.z; return i; }
       i = (i + 1) & mask;
     }
     return KH_NONE;
   } else {
     // two-segment scan of the reference == circular scan; stop at empty, skip deleted
     for (uint64_t step = 0; step <= mask; ++step) {
-      uint32_t b = info[i];
+      const uint4 w = kh_slot_ld(slots + i);
+      const uint32_t b = w.w & 0xFFu;
       if (b == 0x40u) return KH_NONE;
-      if (b < 0x40u && keys[i] == key) return i;
+      if (b < 0x40u && kh_slot_key(w) == key) { if (val_out) *val_out = w.z; return i; }
       i = (i + 1) & mask;
     }
     return KH_NONE;
@@ -84,64 +99,228 @@ __global__ void k_hash_batch(const uint64_t* __restrict__ keys, uint64_t n, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// count / find / erase-mark : one query per lane
+// count / find : a workgroup takes a TILE of KH_Q_TILE queries (dynamic ticket), every lane owns KH_Q_ITEMS of them
+// (query tile_base + j * 256 + tid: a wave's loads and stores of one j are contiguous).  The home buckets of all of a lane's
+// queries are requested before the first one is looked at (8 independent 16-byte loads in flight per lane), and the rare
+// continued probes advance in rounds, again all unresolved queries of the lane at once.
+// find(Iter,Iter) returns the hits only, in query order (hashmap_robinhood.hpp:1194-1268): the compaction happens in the SAME
+// launch.  The hits of a tile are ranked with wave ballots; the tile's position in the output comes from a decoupled
+// look-back over the tiles before it: every tile publishes its hit count as one self-contained 8-byte granule
+// {state, value} (relaxed agent-scope store: the data is the word itself, MI355X guide G16 "R2 granule"), first as an
+// AGGREGATE, then -- once it knows what precedes it -- as an inclusive PREFIX; a tile sums aggregates backwards until it meets
+// a prefix (one wave inspects 64 predecessors per step).  Tiles are handed out by a ticket, so every predecessor has at least
+// been started: the wait is bounded by their run time, not by the dispatcher's order.
 // ---------------------------------------------------------------------------------------------
+#define KH_Q_THREADS 256
+#define KH_Q_ITEMS 8
+#define KH_Q_TILE (KH_Q_THREADS * KH_Q_ITEMS)
+#define KH_LB_AGG (1ull << 62)
+#define KH_LB_PRE (2ull << 62)
+#define KH_LB_VAL ((1ull << 62) - 1ull)
+enum { KH_FIND_PERQUERY = 0, KH_FIND_COMPACT = 1, KH_FIND_PAIRS = 2, KH_FIND_COUNT = 3 };
+
+struct KhFindParams {
+  KhSlots T; const uint64_t* q; uint64_t n; uint64_t seed;
+  uint32_t* out_vals; uint8_t* out_found;          // PERQUERY: value (hits only) + 0/1 flag per query; COUNT: out_found only
+  uint64_t* out_keys; uint8_t* out_pairs16;        // COMPACT: out_keys + out_vals; PAIRS: 16-byte (key, value, 0) records
+  uint32_t* ticket;                                // zero at launch
+  unsigned long long* tile_state;                  // [tiles] zero at launch (COMPACT / PAIRS)
+  unsigned long long* n_found;                     // zero at launch: total hits
+};
+
+// probes the KH_Q_ITEMS queries of this lane; returns the bit mask of hits, vals[j] of the hits
 template <int KIND, int HASH>
-__global__ void k_count(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, uint64_t seed, uint8_t* __restrict__ out) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+__device__ __forceinline__ uint32_t kh_probe_items(const KhSlots& T, const uint64_t (&key)[KH_Q_ITEMS], uint32_t valid, uint64_t seed,
+                                                   uint32_t (&val)[KH_Q_ITEMS]) {
   const uint64_t mask = T.cap - 1;
-  for (; i < n; i += stride) {
-    uint64_t key = q[i];
-    uint64_t pos = kh_find_pos<KIND>(T.keys, T.info, mask, kh_hash64<HASH>(key, seed) & mask, key);
-    out[i] = pos != KH_NONE ? 1 : 0;
+  uint64_t pos[KH_Q_ITEMS];
+  uint4 w[KH_Q_ITEMS];
+#pragma unroll
+  for (int j = 0; j < KH_Q_ITEMS; ++j) pos[j] = kh_hash64<HASH>(key[j], seed) & mask;
+#pragma unroll
+  for (int j = 0; j < KH_Q_ITEMS; ++j) if ((valid >> j) & 1u) w[j] = kh_slot_ld(T.s + pos[j]);
+  uint32_t active = valid, hit = 0;
+  uint32_t dist = 0;                                // every unresolved query of the lane is at the same step
+  while (active) {
+#pragma unroll
+    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+      if (!((active >> j) & 1u)) continue;
+      const uint32_t b = w[j].w & 0xFFu;
+      if (KIND == KHK_RH) {
+        if (0x80u + dist > b) active &= ~(1u << j);                                               // richer resident or empty: absent
+        else if (0x80u + dist == b && kh_slot_key(w[j]) == key[j]) { hit |= 1u << j; val[j] = w[j].z; active &= ~(1u << j); }
+      } else {
+        if (b == 0x40u) active &= ~(1u << j);
+        else if (b < 0x40u && kh_slot_key(w[j]) == key[j]) { hit |= 1u << j; val[j] = w[j].z; active &= ~(1u << j); }
+      }
+    }
+    ++dist;
+    if (KIND == KHK_RH ? dist >= 128u : (uint64_t)dist > mask) break;
+#pragma unroll
+    for (int j = 0; j < KH_Q_ITEMS; ++j) if ((active >> j) & 1u) { pos[j] = (pos[j] + 1) & mask; w[j] = kh_slot_ld(T.s + pos[j]); }
+  }
+  return hit;
+}
+
+template <int KIND, int HASH, int OUT>
+__global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
+  __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_wcnt[KH_Q_ITEMS][KH_Q_THREADS / 64];
+  __shared__ unsigned long long s_prefix;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t ntiles = (uint32_t)((P.n + KH_Q_TILE - 1) / KH_Q_TILE);
+  for (;;) {
+    __syncthreads();                       // s_tile / s_wcnt / s_prefix of the previous tile have been read by every lane
+    if (tid == 0) s_tile = atomicAdd(P.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= ntiles) return;
+    const uint64_t base = (uint64_t)tile * KH_Q_TILE;
+    uint64_t key[KH_Q_ITEMS]; uint32_t val[KH_Q_ITEMS];
+    uint32_t valid = 0;
+#pragma unroll
+    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+      const uint64_t i = base + (uint64_t)j * KH_Q_THREADS + tid;
+      key[j] = 0; val[j] = 0;
+      if (i < P.n) { key[j] = P.q[i]; valid |= 1u << j; }
+    }
+    const uint32_t hit = kh_probe_items<KIND, HASH>(P.T, key, valid, P.seed, val);
+    if (OUT == KH_FIND_PERQUERY || OUT == KH_FIND_COUNT) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int j = 0; j < KH_Q_ITEMS; ++j) {
+        const uint64_t i = base + (uint64_t)j * KH_Q_THREADS + tid;
+        if ((valid >> j) & 1u) {
+          const bool f = (hit >> j) & 1u;
+          P.out_found[i] = f ? 1 : 0;
+          if (OUT == KH_FIND_PERQUERY && f && P.out_vals) P.out_vals[i] = val[j];
+          c += f ? 1u : 0u;
+        }
+      }
+      if (P.n_found) {
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+        if (lane == 0 && c) atomicAdd(P.n_found, (unsigned long long)c);
+      }
+      continue;
+    }
+    // ---- ranks of the hits inside the tile (query order = j-major, then lane)
+    uint32_t before[KH_Q_ITEMS];
+#pragma unroll
+    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+      const unsigned long long m = __ballot((hit >> j) & 1u);
+      before[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wcnt[j][wid] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint32_t off_j[KH_Q_ITEMS];
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+      uint32_t mine = total;
+#pragma unroll
+      for (uint32_t w2 = 0; w2 < KH_Q_THREADS / 64; ++w2) { const uint32_t c = s_wcnt[j][w2]; if (w2 < wid) mine += c; total += c; }
+      off_j[j] = mine;
+    }
+    // ---- decoupled look-back (wave 0): exclusive prefix of this tile over the tiles before it
+    if (wid == 0) {
+      if (lane == 0 && tile + 1 < ntiles)
+        __hip_atomic_store(&P.tile_state[tile], (tile == 0 ? KH_LB_PRE : KH_LB_AGG) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long excl = 0;
+      int64_t look = (int64_t)tile - 1;             // lane l inspects tile look - l
+      unsigned long long st = 0;
+      while (look >= 0) {
+        const int64_t t = look - (int64_t)lane;
+        // (re)load only what has not been seen published yet: 1280 resident workgroups x 64 lanes polling in a tight loop
+        // would keep the L2 busier than the probes do (MI355X guide, polling-cost)
+        if (t < 0) st = KH_LB_PRE;                  // lanes before tile 0 behave as a zero prefix
+        else if (!(st >> 62)) st = __hip_atomic_load(&P.tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ready = __ballot((st >> 62) != 0ull);
+        const unsigned long long pre = __ballot((st >> 62) == 2ull);
+        const uint32_t first_nr = ~ready ? (uint32_t)__ffsll((long long)~ready) - 1u : 64u;
+        const uint32_t first_pre = pre ? (uint32_t)__ffsll((long long)pre) - 1u : 64u;
+        if (first_pre < first_nr) {                 // a prefix with every aggregate between it and this tile: done
+          unsigned long long v = lane <= first_pre ? (st & KH_LB_VAL) : 0ull;
+          for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+          excl += v;
+          break;
+        }
+        if (first_nr == 64u) {                      // 64 aggregates, no prefix among them: next window
+          unsigned long long v = st & KH_LB_VAL;
+          for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+          excl += v;
+          look -= 64;
+          st = 0;
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(20);               // a predecessor is still probing: ~0.5 us, then look again
+      }
+      if (lane == 0) {
+        if (tile != 0 && tile + 1 < ntiles)
+          __hip_atomic_store(&P.tile_state[tile], KH_LB_PRE | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile + 1 == ntiles) *P.n_found = excl + total;
+        s_prefix = excl;
+      }
+    }
+    __syncthreads();
+    const unsigned long long obase = s_prefix;
+#pragma unroll
+    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+      if ((hit >> j) & 1u) {
+        const unsigned long long o = obase + off_j[j] + before[j];
+        if (OUT == KH_FIND_PAIRS) {
+          uint4 w; w.x = (uint32_t)key[j]; w.y = (uint32_t)(key[j] >> 32); w.z = val[j]; w.w = 0;
+          *reinterpret_cast<uint4*>(P.out_pairs16 + o * 16) = w;
+        } else {
+          P.out_keys[o] = key[j];
+          P.out_vals[o] = val[j];
+        }
+      }
+    }
   }
 }
 
-template <int KIND, int HASH>
-__global__ void k_find(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, uint64_t seed,
-                       uint32_t* __restrict__ out_vals, uint8_t* __restrict__ out_found) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t mask = T.cap - 1;
-  for (; i < n; i += stride) {
-    uint64_t key = q[i];
-    uint64_t pos = kh_find_pos<KIND>(T.keys, T.info, mask, kh_hash64<HASH>(key, seed) & mask, key);
-    bool f = pos != KH_NONE;
-    out_found[i] = f ? 1 : 0;
-    if (f) out_vals[i] = T.vals[pos];
-  }
-}
-
-// RH: the table is not modified; hits are recorded in a bitmask (one bit per slot) and the table is
-//     then re-laid-out without them (== backward-shift deletion, hashmap_robinhood.hpp:1294-1356).
+// RH: hits are MARKED in the slot's info word (bit 8: invisible to probes) and the table is then re-laid-out without the
+//     marked elements (== backward-shift deletion, hashmap_robinhood.hpp:1294-1356).
 // LP: tombstone in place (info = 0x80), hashmap_linearprobe.hpp:911-978.
 // A key listed twice in the batch erases once: the atomic decides who counts it.
 template <int KIND, int HASH>
-__global__ void k_erase_mark(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, uint64_t seed,
-                             uint32_t* __restrict__ erased_bits, unsigned long long* __restrict__ n_erased) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+__global__ __launch_bounds__(KH_Q_THREADS) void k_erase_mark(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, uint64_t seed,
+                                                          unsigned long long* __restrict__ n_erased) {
   const uint64_t mask = T.cap - 1;
+  const uint64_t stride = (uint64_t)gridDim.x * KH_Q_THREADS;
   uint32_t mine = 0;
-  for (; i < n; i += stride) {
-    uint64_t key = q[i];
-    uint64_t pos = kh_find_pos<KIND>(T.keys, T.info, mask, kh_hash64<HASH>(key, seed) & mask, key);
+  for (uint64_t i = (uint64_t)blockIdx.x * KH_Q_THREADS + threadIdx.x; i < n; i += stride) {
+    const uint64_t key = q[i];
+    const uint64_t pos = kh_find_pos<KIND>(T.s, mask, kh_hash64<HASH>(key, seed) & mask, key);
     if (pos == KH_NONE) continue;
     if (KIND == KHK_RH) {
-      uint32_t bit = 1u << (pos & 31);
-      uint32_t old = atomicOr(&erased_bits[pos >> 5], bit);
-      if (!(old & bit)) ++mine;
+      const uint32_t old = atomicOr(&T.s[pos].info, KH_INFO_ERASE_MARK);
+      if (!(old & KH_INFO_ERASE_MARK)) ++mine;
     } else {
-      uint32_t* w = reinterpret_cast<uint32_t*>(T.info) + (pos >> 2);
-      uint32_t sh = (uint32_t)(pos & 3) * 8;
-      uint32_t old = atomicOr(w, 0x80u << sh);
-      if (((old >> sh) & 0xFFu) < 0x40u) ++mine;
+      const uint32_t old = atomicOr(&T.s[pos].info, 0x80u);
+      if ((old & 0xFFu) < 0x40u) ++mine;
     }
   }
   // wave reduction, one atomic per wave
   for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_erased, (unsigned long long)mine);
+}
+// a batch erase whose re-layout could not run (no memory for the new buffer) takes its marks back
+__global__ void k_clear_marks(KhSlots T) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.cap; i += stride)
+    if (T.s[i].info & KH_INFO_ERASE_MARK) T.s[i].info &= 0xFFu;
+}
+// every slot of a table empty (kh_create, clear(); re-layouts write each slot of their destination themselves)
+template <int KIND>
+__global__ void k_fill_empty(KhSlots T) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.cap; i += stride) kh_slot_st(T.s + i, 0, 0, kh_empty_info<KIND>());
+}
+// test hook (KH_DEBUG_POISON): a destination buffer starts as garbage that no probe would accept as empty
+__global__ void k_poison(KhSlots T) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < T.cap; i += stride) kh_slot_st(T.s + i, 0xEEEEEEEEEEEEEEEEull, 0xEEEEEEEEu, 0xEEu);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -809,12 +988,13 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
         if (x < ns && ((rep_mask >> it) & 1u)) {
           key = lk[x]; iv = liv[x];
           uint64_t at = KH_NONE;
+          uint32_t cur_val = 0;
           if (!P.table_empty) {
             const uint64_t h = kh_hash64<HASH>(key, P.seed);
-            at = kh_find_pos<KIND>(P.T.keys, P.T.info, mask, h & mask, key);
+            at = kh_find_pos<KIND>(P.T.s, mask, h & mask, key, &cur_val);
           }
-          if (P.mode == KH_DEDUP_LAST) { if (at != KH_NONE) P.T.vals[at] = (uint32_t)iv; }   // kh_update's assign pass: store the LAST value
-          else if (P.mode == KH_DEDUP_PLUS && at != KH_NONE) P.T.vals[at] += (uint32_t)iv;       // one lane per distinct key: no race
+          if (P.mode == KH_DEDUP_LAST) { if (at != KH_NONE) P.T.s[at].val = (uint32_t)iv; }   // kh_update's assign pass: store the LAST value
+          else if (P.mode == KH_DEDUP_PLUS && at != KH_NONE) P.T.s[at].val = cur_val + (uint32_t)iv;   // one lane per distinct key: no race
           else emit = at == KH_NONE;
         }
         const uint32_t pos = kh_wave_append(emit, &out_count);
@@ -882,7 +1062,7 @@ __global__ void k_gather_new(const uint64_t* __restrict__ part_off, const uint64
 // ---------------------------------------------------------------------------------------------
 struct KhRebuildParams {
   KhSlots Old;                       // source table
-  const uint32_t* erased_bits;       // optional: slots to drop (RH erase)
+  int drop_marked;                   // RH erase: elements whose info word carries KH_INFO_ERASE_MARK are left out
   KhSlots New;                       // destination table (info pre-set to "empty")
   const uint64_t* ck; const uint32_t* cv;   // new distinct elements, grouped by partition
   const uint64_t* noff;              // [nparts+1] start of every partition's list in ck/cv (null: no new elements)
@@ -925,7 +1105,7 @@ __device__ __forceinline__ void kh_for_each_old(const KhRebuildParams& P, uint32
         if (tid == 0) *s_emin = window;
         __syncthreads();
         for (uint32_t t = tid; t < window; t += KH_CHUNK_THREADS) {
-          if (kh_is_empty<KIND>(P.Old.info[(S + Lo + base + t) & mask_o])) { atomicMin(s_emin, t); break; }
+          if (kh_is_empty<KIND>(P.Old.s[(S + Lo + base + t) & mask_o].info & 0xFFu)) { atomicMin(s_emin, t); break; }
         }
         __syncthreads();
         const uint32_t e = *s_emin;
@@ -936,14 +1116,14 @@ __device__ __forceinline__ void kh_for_each_old(const KhRebuildParams& P, uint32
     (void)spill_max;
     const uint64_t len = (uint64_t)Lo + e_total;
     for (uint64_t t = tid; t < len; t += KH_CHUNK_THREADS) {
-      const uint64_t s = (S + t) & mask_o;
-      if (!kh_is_occupied<KIND>(P.Old.info[s])) continue;
-      if (P.erased_bits && ((P.erased_bits[s >> 5] >> (s & 31)) & 1u)) continue;
-      const uint64_t key = P.Old.keys[s];
+      const uint4 w = kh_slot_ld(P.Old.s + ((S + t) & mask_o));
+      if (!kh_is_occupied<KIND>(w.w & 0xFFu)) continue;
+      if (P.drop_marked && (w.w & KH_INFO_ERASE_MARK)) continue;
+      const uint64_t key = kh_slot_key(w);
       const uint64_t h = kh_hash64<HASH>(key, P.seed);
       if ((uint32_t)((h & mask_o) >> KH_LB) != o) continue;          // belongs to a neighbouring old chunk
       if ((uint32_t)((h & mask_n) >> KH_LB) != c) continue;          // goes to another new chunk (growing)
-      f(key, P.Old.vals[s], h & mask_n);
+      f(key, w.z, h & mask_n);
     }
     if (nch_o < nch_n) break;
   }
@@ -1114,10 +1294,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParam
       ib = (uint8_t)(0x80u | dist);
     }
     if (prel < KH_L + KH_SPILL) { skeys[prel] = key; svals[prel] = val; sinfo[prel] = ib; }
-    else {
-      uint64_t pos = (Sc + prel) & mask_n;
-      P.New.keys[pos] = key; P.New.vals[pos] = val; P.New.info[pos] = ib;
-    }
+    else kh_slot_st(P.New.s + ((Sc + prel) & mask_n), key, val, ib);
   };
   kh_for_each_old<KIND, HASH>(P, c, &s_emin, place);
   kh_for_each_new<HASH>(P, c, place);
@@ -1129,10 +1306,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParam
   const uint32_t lo = xr > 0 ? (uint32_t)xr : 0u;
   uint32_t hi = pend < (long long)(KH_L + KH_SPILL) ? (uint32_t)pend : (KH_L + KH_SPILL);
   for (uint32_t s0 = lo + tid; s0 < hi; s0 += KH_CHUNK_THREADS) {
-    const uint64_t pos = (Sc + s0) & mask_n;
-    P.New.keys[pos] = skeys[s0];
-    P.New.vals[pos] = svals[s0];
-    P.New.info[pos] = sinfo[s0];
+    kh_slot_st(P.New.s + ((Sc + s0) & mask_n), skeys[s0], svals[s0], sinfo[s0]);
   }
 }
 
@@ -1206,7 +1380,7 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
         if (tid == 0) *scratch = window;
         __syncthreads();
         for (uint32_t t = tid; t < window; t += KH_CHUNK_THREADS) {
-          if (R.Old.info[(S + KH_L + base + t) & mask_o] == 0x40u) { atomicMin(scratch, t); break; }
+          if ((R.Old.s[(S + KH_L + base + t) & mask_o].info & 0xFFu) == 0x40u) { atomicMin(scratch, t); break; }
         }
         __syncthreads();
         const uint32_t e = *scratch;
@@ -1218,43 +1392,36 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
       len = KH_L + e_total;
     }
     if (KIND == KHK_RH) {
-      // the 2176 candidate slots are 4.25 per lane: all info bytes are requested at once, then all keys, then all values
-      // (three dependent HBM round trips per chunk instead of up to fifteen)
+      // the 2176 candidate slots are 4.25 per lane: all of them are requested at once, one 16-byte load each (key, value and
+      // info byte arrive together: one HBM round trip per chunk)
       constexpr uint32_t NS = (KH_L + 128u + KH_CHUNK_THREADS - 1) / KH_CHUNK_THREADS;
-      uint32_t inf[NS], hrel[NS], valv[NS], cand = 0, takem = 0;
-      uint64_t keyv[NS];
+      uint4 w[NS];
 #pragma unroll
       for (uint32_t it = 0; it < NS; ++it) {
         const uint32_t t = it * KH_CHUNK_THREADS + tid;
-        inf[it] = t < KH_L + 128u ? R.Old.info[(S + t) & mask_o] : 0u;
+        w[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (t < KH_L + 128u) w[it] = kh_slot_ld(R.Old.s + ((S + t) & mask_o));
       }
 #pragma unroll
       for (uint32_t it = 0; it < NS; ++it) {
         const uint64_t sl = (S + it * KH_CHUNK_THREADS + tid) & mask_o;
-        keyv[it] = 0; hrel[it] = 0;
-        if (inf[it] >= 0x80u && !(R.erased_bits && ((R.erased_bits[sl >> 5] >> (sl & 31)) & 1u))) {
-          const uint64_t home_o = (sl - (inf[it] & 0x7Fu)) & mask_o;
-          if ((uint32_t)(home_o >> KH_LB) == o) { cand |= 1u << it; hrel[it] = (uint32_t)(home_o - S); keyv[it] = R.Old.keys[sl]; }
-        }
-      }
-#pragma unroll
-      for (uint32_t it = 0; it < NS; ++it) {
-        valv[it] = 0;
-        if ((cand >> it) & 1u) {
-          bool mine = true;
-          if (!same) {
-            const uint64_t hn = kh_hash64<HASH>(keyv[it], R.seed) & mask_n;
-            mine = (uint32_t)(hn >> KH_LB) == c;
-            hrel[it] = (uint32_t)(hn - Sc);
+        const uint32_t inf = w[it].w & 0xFFu;
+        bool take = false;
+        uint32_t hrel = 0;
+        const uint64_t key = kh_slot_key(w[it]);
+        if (inf >= 0x80u && !(R.drop_marked && (w[it].w & KH_INFO_ERASE_MARK))) {
+          const uint64_t home_o = (sl - (inf & 0x7Fu)) & mask_o;
+          if ((uint32_t)(home_o >> KH_LB) == o) {
+            if (same) { take = true; hrel = (uint32_t)(home_o - S); }
+            else {
+              const uint64_t hn = kh_hash64<HASH>(key, R.seed) & mask_n;
+              take = (uint32_t)(hn >> KH_LB) == c;
+              hrel = (uint32_t)(hn - Sc);
+            }
           }
-          if (mine) { takem |= 1u << it; valv[it] = R.Old.vals[(S + it * KH_CHUNK_THREADS + tid) & mask_o]; }
         }
-      }
-#pragma unroll
-      for (uint32_t it = 0; it < NS; ++it) {
-        const bool take = (takem >> it) & 1u;
         const uint32_t x = kh_wave_append(take, n_staged);
-        if (take && x < KH_DD_M) { lk[x] = keyv[it]; liv[x] = MERGE ? (unsigned long long)valv[it] : (((unsigned long long)hrel[it] << 32) | valv[it]); }
+        if (take && x < KH_DD_M) { lk[x] = key; liv[x] = MERGE ? (unsigned long long)w[it].z : (((unsigned long long)hrel << 32) | w[it].z); }
       }
     } else
     for (uint64_t t0 = 0; t0 < len; t0 += KH_CHUNK_THREADS) {
@@ -1262,22 +1429,12 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
       bool take = false;
       uint64_t key = 0; uint32_t val = 0, hrel = 0;
       if (t < len) {
-        const uint64_t sl = (S + t) & mask_o;
-        const uint32_t inf = R.Old.info[sl];
-        if (KIND == KHK_RH) {
-          if (inf >= 0x80u && !(R.erased_bits && ((R.erased_bits[sl >> 5] >> (sl & 31)) & 1u))) {
-            const uint64_t home_o = (sl - (inf & 0x7Fu)) & mask_o;
-            if ((uint32_t)(home_o >> KH_LB) == o) {
-              key = R.Old.keys[sl];
-              const uint64_t hn = same ? home_o : (kh_hash64<HASH>(key, R.seed) & mask_n);
-              if ((uint32_t)(hn >> KH_LB) == c) { take = true; val = R.Old.vals[sl]; hrel = (uint32_t)(hn - Sc); }
-            }
-          }
-        } else if (inf < 0x40u) {
-          key = R.Old.keys[sl];
+        const uint4 w = kh_slot_ld(R.Old.s + ((S + t) & mask_o));
+        if ((w.w & 0xFFu) < 0x40u) {
+          key = kh_slot_key(w);
           const uint64_t h = kh_hash64<HASH>(key, R.seed);
           if ((uint32_t)((h & mask_o) >> KH_LB) == o && (uint32_t)((h & mask_n) >> KH_LB) == c) {
-            take = true; val = R.Old.vals[sl]; hrel = (uint32_t)((h & mask_n) - Sc);
+            take = true; val = w.z; hrel = (uint32_t)((h & mask_n) - Sc);
           }
         }
       }
@@ -1525,11 +1682,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       uint32_t dist = prel - b;
       if (KIND == KHK_RH && dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
       if (prel < KH_L + KH_FSPILL) simg[prel] = (uint16_t)(x | ((dist < 31u ? dist : 31u) << 11));   // record index | distance code
-      else {
-        const uint64_t pos = (Sc + prel) & mask_n;
-        P.New.keys[pos] = lk[x]; P.New.vals[pos] = (uint32_t)liv[x];
-        P.New.info[pos] = KIND == KHK_RH ? (uint8_t)(0x80u | dist) : (uint8_t)0x00;
-      }
+      else kh_slot_st(P.New.s + ((Sc + prel) & mask_n), lk[x], (uint32_t)liv[x], KIND == KHK_RH ? (0x80u | dist) : 0x00u);
     }
   }
   __syncthreads();
@@ -1538,24 +1691,22 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   const uint32_t lo = (uint32_t)xr;
   const uint32_t hi = pend < (long long)(KH_L + KH_FSPILL) ? (uint32_t)pend : (KH_L + KH_FSPILL);
   for (uint32_t s0 = lo + tid; s0 < hi; s0 += KH_CHUNK_THREADS) {
-    const uint64_t pos = (Sc + s0) & mask_n;
+    KhSlot* dst = P.New.s + ((Sc + s0) & mask_n);
     const uint32_t e = simg[s0];
-    if (e == 0xFFFFu) {
-      P.New.keys[pos] = 0; P.New.vals[pos] = 0;
-      P.New.info[pos] = KIND == KHK_RH ? (uint8_t)0x00 : (uint8_t)0x40;
-    } else {
+    if (e == 0xFFFFu) kh_slot_st(dst, 0, 0, kh_empty_info<KIND>());
+    else {
       const uint32_t x = e & 0x7FFu;
       const uint64_t key = lk[x];
-      P.New.keys[pos] = key;
-      P.New.vals[pos] = (uint32_t)liv[x];
+      uint32_t ib = 0x00u;
       if (KIND == KHK_RH) {     // distance = slot - home: the 5-bit code next to the record index; the rare long ones are re-derived from the key
         uint32_t dist = e >> 11;
         if (dist == 31u) {
           dist = s0 - (uint32_t)((kh_hash64<HASH>(key, P.seed) & mask_n) - Sc);
           if (dist > 127u) dist = 127u;
         }
-        P.New.info[pos] = (uint8_t)(0x80u | dist);
-      } else P.New.info[pos] = 0x00;
+        ib = 0x80u | dist;
+      }
+      kh_slot_st(dst, key, (uint32_t)liv[x], ib);      // one coalesced 16-byte store per slot: key, value and info byte together
     }
   }
 }
@@ -1585,23 +1736,31 @@ __global__ __launch_bounds__(1024) void k_fused_totals(const unsigned long long*
 }
 
 // RH displacement histogram (REPROBE_STAT-style oracle)
-__global__ void k_disp_hist(const uint8_t* __restrict__ info, uint64_t cap, unsigned long long* __restrict__ out128) {
+__global__ void k_disp_hist(const KhSlot* __restrict__ slots, uint64_t cap, unsigned long long* __restrict__ out128) {
   __shared__ uint32_t h[128];
   if (threadIdx.x < 128) h[threadIdx.x] = 0;
   __syncthreads();
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < cap; i += stride) { uint32_t b = info[i]; if (b >= 0x80u) atomicAdd(&h[b & 0x7Fu], 1u); }
+  for (; i < cap; i += stride) { uint32_t b = slots[i].info & 0xFFu; if (b >= 0x80u) atomicAdd(&h[b & 0x7Fu], 1u); }
   __syncthreads();
   if (threadIdx.x < 128 && h[threadIdx.x]) atomicAdd(&out128[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
-// occupied (key,value) pairs in slot order: flags for the generic compaction
+// SoA view of the table for the host-side exports (to_vector, export_info, export_slots): keys / values / info bytes and the
+// occupied flags the generic compaction takes; any output may be null
 template <int KIND>
-__global__ void k_occupied_flags(const uint8_t* __restrict__ info, uint64_t cap, uint8_t* __restrict__ flags) {
+__global__ void k_unpack_slots(const KhSlot* __restrict__ slots, uint64_t cap, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                               uint8_t* __restrict__ info, uint8_t* __restrict__ flags) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; i < cap; i += stride) flags[i] = kh_is_occupied<KIND>(info[i]) ? 1 : 0;
+  for (; i < cap; i += stride) {
+    const uint4 w = kh_slot_ld(slots + i);
+    if (keys) keys[i] = kh_slot_key(w);
+    if (vals) vals[i] = w.z;
+    if (info) info[i] = (uint8_t)(w.w & 0xFFu);
+    if (flags) flags[i] = kh_is_occupied<KIND>(w.w & 0xFFu) ? 1 : 0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1887,6 +2046,7 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
                               uint32_t* __restrict__ flags) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const uint64_t mask = T.cap - 1;
+  KhSlot* const S = T.s;
   unsigned long long changed = 0;
   uint32_t i = 0;
   for (; i < n; ++i) {
@@ -1898,26 +2058,29 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
       uint32_t reprobe = 0x80u;
       bool found = false;
       for (;;) {
-        const uint32_t inf = T.info[p];
+        const uint4 w = kh_slot_ld(S + p);
+        const uint32_t inf = w.w & 0xFFu;
         if (inf < reprobe) break;
-        if (inf == reprobe && T.keys[p] == key) { found = true; break; }
+        if (inf == reprobe && kh_slot_key(w) == key) { found = true; break; }
         ++reprobe; p = (p + 1) & mask;
         if (reprobe > 0xFFu) break;
       }
       if (op == KH_SMALL_ERASE) {
         if (!found) continue;
         uint64_t q = (p + 1) & mask;
-        while (T.info[q] > 0x80u) {                       // occupied, distance >= 1: moves one slot towards its home
-          T.keys[p] = T.keys[q]; T.vals[p] = T.vals[q]; T.info[p] = (uint8_t)(T.info[q] - 1u);
+        for (;;) {                                          // occupied, distance >= 1: moves one slot towards its home
+          const uint4 w = kh_slot_ld(S + q);
+          if ((w.w & 0xFFu) <= 0x80u) break;
+          kh_slot_st(S + p, kh_slot_key(w), w.z, (w.w & 0xFFu) - 1u);
           p = q; q = (q + 1) & mask;
         }
-        T.info[p] = 0x00;
+        kh_slot_st(S + p, 0, 0, 0x00u);
         ++changed;
         continue;
       }
       if (found) {
-        if (op == KH_SMALL_UPDATE) T.vals[p] = val;
-        else if (op == KH_SMALL_PLUS) T.vals[p] += val;
+        if (op == KH_SMALL_UPDATE) S[p].val = val;
+        else if (op == KH_SMALL_PLUS) S[p].val += val;
         continue;
       }
       if (reprobe > 0xFFu) break;                         // would sit past distance 127: general path decides
@@ -1925,7 +2088,7 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
       {
         uint64_t pp = p; uint32_t r = reprobe; bool over = false;
         for (;;) {
-          const uint32_t cur = T.info[pp];
+          const uint32_t cur = S[pp].info & 0xFFu;
           if (cur == 0x00u) break;
           if (cur < r) r = cur;                           // the resident is displaced and travels on with its own distance
           ++r; pp = (pp + 1) & mask;
@@ -1936,12 +2099,12 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
       // ---- insert with displacement
       uint64_t ck = key; uint32_t cv = val; uint32_t r = reprobe;
       for (;;) {
-        const uint32_t cur = T.info[p];
-        if (cur == 0x00u) { T.keys[p] = ck; T.vals[p] = cv; T.info[p] = (uint8_t)r; break; }
+        const uint4 w = kh_slot_ld(S + p);
+        const uint32_t cur = w.w & 0xFFu;
+        if (cur == 0x00u) { kh_slot_st(S + p, ck, cv, r); break; }
         if (cur < r) {
-          const uint64_t tk = T.keys[p]; const uint32_t tv = T.vals[p];
-          T.keys[p] = ck; T.vals[p] = cv; T.info[p] = (uint8_t)r;
-          ck = tk; cv = tv; r = cur;
+          kh_slot_st(S + p, ck, cv, r);
+          ck = kh_slot_key(w); cv = w.z; r = cur;
         }
         ++r; p = (p + 1) & mask;
       }
@@ -1951,19 +2114,20 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
       uint64_t ins = KH_NONE;
       bool found = false;
       for (uint64_t step = 0; step < T.cap; ++step) {
-        const uint32_t inf = T.info[p];
+        const uint4 w = kh_slot_ld(S + p);
+        const uint32_t inf = w.w & 0xFFu;
         if (inf == 0x40u) { if (ins == KH_NONE) ins = p; break; }
         if (inf >= 0x80u) { if (ins == KH_NONE) ins = p; }
-        else if (T.keys[p] == key) { found = true; break; }
+        else if (kh_slot_key(w) == key) { found = true; break; }
         p = (p + 1) & mask;
       }
       if (found) {
-        if (op == KH_SMALL_UPDATE) T.vals[p] = val;
-        else if (op == KH_SMALL_PLUS) T.vals[p] += val;
+        if (op == KH_SMALL_UPDATE) S[p].val = val;
+        else if (op == KH_SMALL_PLUS) S[p].val += val;
         continue;
       }
       if (ins == KH_NONE) { atomicOr(&flags[KH_FLAG_INTERNAL], 1u); break; }     // full table: cannot happen below max_load
-      T.keys[ins] = key; T.vals[ins] = val; T.info[ins] = 0x00;
+      kh_slot_st(S + ins, key, val, 0x00u);
       ++changed;
     }
   }
@@ -1971,3 +2135,166 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
   out[1] = i;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Batches of middle size (10^2 .. 10^6 keys) into a LARGE Robin Hood table, in place.  The reference inserts such a batch
+// in O(batch) (hashmap_robinhood.hpp:522-624); re-laying out the whole table for it costs O(table) (1.3-1.8 ms at 2^27
+// buckets: 10^4 keys would run slower than one CPU thread).  Here the table is cut into REGIONS of KH_L consecutive slots and
+// every region is owned by ONE lane, which applies the keys whose home bucket lies in its region one after the other with
+// the reference's single-key algorithms -- insert with displacement, backward-shift erase.  An operation that would read or
+// write a slot outside the owner's region (the displacement chain or the shift runs over the region's end) is not started:
+// the key goes to a deferred list.  No slot is touched by two lanes of one launch, so no inter-workgroup visibility is
+// needed inside a launch (per-XCD L2s are not coherent with each other).  The deferred keys (about 0.5 %: a chain crosses
+// a given boundary with probability ~ cluster length / 2048) are binned again with the regions shifted by half a region --
+// the old boundaries are interior now -- and what is deferred a second time (~0.003 %) is applied by a single lane.
+// The keys of an insert are DISTINCT and ABSENT from the table (k_dedup has folded duplicates and tested membership), so the
+// order in which they are applied does not matter: the Robin Hood layout is a function of the key set alone.
+// ---------------------------------------------------------------------------------------------
+#define KH_IP_CAP 16             // keys binned per region and pass; more go to the deferred list
+enum { KH_IP_INSERT = 0, KH_IP_ERASE = 1 };
+enum { KH_IP_DONE = 0, KH_IP_LEAVES_REGION = 1, KH_IP_TOO_FAR = 2, KH_IP_ABSENT = 3 };
+
+// Robin Hood insert of a key known to be absent (hashmap_robinhood.hpp:522-624 without the equality test).  BOUNDED: every
+// slot looked at must lie in [reg_start, reg_start + KH_L) (circular), otherwise nothing is written.
+template <bool BOUNDED>
+__device__ __forceinline__ int kh_rh_insert_absent(KhSlot* S, uint64_t mask, uint64_t home, uint64_t key, uint32_t val, uint64_t reg_start) {
+  uint64_t p = home;
+  uint32_t r = 0x80u;
+  // the slot the key takes: the first one whose resident is richer (closer to its home) or that is empty
+  for (;;) {
+    if (BOUNDED && ((p - reg_start) & mask) >= KH_L) return KH_IP_LEAVES_REGION;
+    const uint32_t inf = S[p].info & 0xFFu;
+    if (inf < r) break;
+    ++r; p = (p + 1) & mask;
+    if (r > 0xFFu) return KH_IP_TOO_FAR;
+  }
+  // dry run of the displacement chain: distances only
+  {
+    uint64_t pp = p; uint32_t rr = r;
+    for (;;) {
+      if (BOUNDED && ((pp - reg_start) & mask) >= KH_L) return KH_IP_LEAVES_REGION;
+      const uint32_t cur = S[pp].info & 0xFFu;
+      if (cur == 0x00u) break;
+      if (cur < rr) rr = cur;                           // the resident is displaced and travels on with its own distance
+      ++rr; pp = (pp + 1) & mask;
+      if (rr > 0xFFu) return KH_IP_TOO_FAR;
+    }
+  }
+  uint64_t ck = key; uint32_t cv = val;
+  for (;;) {
+    const uint4 w = kh_slot_ld(S + p);
+    const uint32_t cur = w.w & 0xFFu;
+    if (cur == 0x00u) { kh_slot_st(S + p, ck, cv, r); break; }
+    if (cur < r) {
+      kh_slot_st(S + p, ck, cv, r);
+      ck = kh_slot_key(w); cv = w.z; r = cur;
+    }
+    ++r; p = (p + 1) & mask;
+  }
+  return KH_IP_DONE;
+}
+
+// Robin Hood erase by backward shift (hashmap_robinhood.hpp:1294-1356)
+template <bool BOUNDED>
+__device__ __forceinline__ int kh_rh_erase_one(KhSlot* S, uint64_t mask, uint64_t home, uint64_t key, uint64_t reg_start) {
+  uint64_t p = home;
+  uint32_t r = 0x80u;
+  for (;;) {
+    if (BOUNDED && ((p - reg_start) & mask) >= KH_L) return KH_IP_LEAVES_REGION;
+    const uint4 w = kh_slot_ld(S + p);
+    const uint32_t inf = w.w & 0xFFu;
+    if (inf < r) return KH_IP_ABSENT;
+    if (inf == r && kh_slot_key(w) == key) break;
+    ++r; p = (p + 1) & mask;
+    if (r > 0xFFu) return KH_IP_ABSENT;
+  }
+  if (BOUNDED) {     // the shift ends at the first slot that is empty or holds an element at its home: it must be ours to read
+    uint64_t q = (p + 1) & mask;
+    for (;;) {
+      if (((q - reg_start) & mask) >= KH_L) return KH_IP_LEAVES_REGION;
+      if ((S[q].info & 0xFFu) <= 0x80u) break;
+      q = (q + 1) & mask;
+    }
+  }
+  uint64_t q = (p + 1) & mask;
+  for (;;) {
+    const uint4 w = kh_slot_ld(S + q);
+    if ((w.w & 0xFFu) <= 0x80u) break;
+    kh_slot_st(S + p, kh_slot_key(w), w.z, (w.w & 0xFFu) - 1u);
+    p = q; q = (q + 1) & mask;
+  }
+  kh_slot_st(S + p, 0, 0, 0x00u);
+  return KH_IP_DONE;
+}
+
+struct KhInplaceParams {
+  KhSlots T; uint64_t seed;
+  uint32_t ofs;                            // region r = slots [r * KH_L + ofs, (r + 1) * KH_L + ofs), circular
+  const ulonglong2* in_rec;                // input list as (key, value) records, or
+  const uint64_t* in_k; const uint32_t* in_v;   //   as key / value arrays (in_v null: values 0)
+  uint64_t n; const unsigned long long* n_dev;  // list length: n_dev != null overrides n (a count produced on the device)
+  uint32_t* cnt;                           // [regions] zero at launch
+  ulonglong2* bins;                        // [regions * KH_IP_CAP]
+  ulonglong2* defer; unsigned long long* n_defer;      // keys not applied by this pass (n_defer zero at launch)
+  unsigned long long* n_done;              // keys inserted / erased (accumulates over the passes)
+  uint32_t* flags;
+};
+
+template <int HASH>
+__global__ void k_ip_bin(KhInplaceParams P) {
+  const uint64_t n = P.n_dev ? (uint64_t)*P.n_dev : P.n;
+  const uint64_t mask = P.T.cap - 1;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    ulonglong2 rec;
+    if (P.in_rec) rec = P.in_rec[i];
+    else { rec.x = P.in_k[i]; rec.y = P.in_v ? P.in_v[i] : 0u; }
+    const uint64_t home = kh_hash64<HASH>(rec.x, P.seed) & mask;
+    const uint32_t r = (uint32_t)(((home - P.ofs) & mask) >> KH_LB);
+    const uint32_t rank = atomicAdd(&P.cnt[r], 1u);
+    if (rank < KH_IP_CAP) P.bins[(uint64_t)r * KH_IP_CAP + rank] = rec;
+    else P.defer[atomicAdd(P.n_defer, 1ull)] = rec;
+  }
+}
+
+// one LANE per region
+template <int HASH, int OP>
+__global__ void k_ip_apply(KhInplaceParams P) {
+  const uint64_t mask = P.T.cap - 1;
+  const uint32_t regions = (uint32_t)(P.T.cap >> KH_LB);
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t done = 0;
+  if (r < regions) {
+    const uint32_t c = P.cnt[r] < KH_IP_CAP ? P.cnt[r] : KH_IP_CAP;
+    const uint64_t reg_start = ((uint64_t)r * KH_L + P.ofs) & mask;
+    for (uint32_t j = 0; j < c; ++j) {
+      const ulonglong2 rec = P.bins[(uint64_t)r * KH_IP_CAP + j];
+      const uint64_t home = kh_hash64<HASH>(rec.x, P.seed) & mask;
+      const int st = OP == KH_IP_INSERT ? kh_rh_insert_absent<true>(P.T.s, mask, home, rec.x, (uint32_t)rec.y, reg_start)
+                                        : kh_rh_erase_one<true>(P.T.s, mask, home, rec.x, reg_start);
+      if (st == KH_IP_DONE) ++done;
+      else if (st == KH_IP_LEAVES_REGION) P.defer[atomicAdd(P.n_defer, 1ull)] = rec;
+      else if (st == KH_IP_TOO_FAR) atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) done += __shfl_down(done, off, 64);
+  if ((threadIdx.x & 63) == 0 && done) atomicAdd(P.n_done, (unsigned long long)done);
+}
+
+// what two binned passes could not place: one lane, unbounded
+template <int HASH, int OP>
+__global__ void k_ip_serial(KhInplaceParams P) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint64_t n = P.n_dev ? (uint64_t)*P.n_dev : P.n;
+  const uint64_t mask = P.T.cap - 1;
+  unsigned long long done = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const ulonglong2 rec = P.in_rec[i];
+    const uint64_t home = kh_hash64<HASH>(rec.x, P.seed) & mask;
+    const int st = OP == KH_IP_INSERT ? kh_rh_insert_absent<false>(P.T.s, mask, home, rec.x, (uint32_t)rec.y, 0)
+                                      : kh_rh_erase_one<false>(P.T.s, mask, home, rec.x, 0);
+    if (st == KH_IP_DONE) ++done;
+    else if (st == KH_IP_TOO_FAR) atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u);
+  }
+  if (done) atomicAdd(P.n_done, done);
+}

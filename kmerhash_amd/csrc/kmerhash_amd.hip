@@ -209,37 +209,46 @@ void arena_consolidate(kh_table*) {}
   } while (0)
 
 // ---- slots ---------------------------------------------------------------------------------------
-uint8_t empty_byte(int kind) { return kind == KHK_RH ? 0x00 : 0x40; }
+const KhSlots kNoSlots = KhSlots{nullptr, 0};
+const bool g_poison = getenv("KH_DEBUG_POISON") != nullptr;      // test hook: destination buffers start as garbage
 void free_slots(kh_table* t, KhSlots& s) {
-  pool_free(t->device, s.keys);
-  pool_free(t->device, s.vals);
-  pool_free(t->device, s.info);
-  s.keys = nullptr; s.vals = nullptr; s.info = nullptr; s.cap = 0;
+  pool_free(t->device, s.s);
+  s = kNoSlots;
 }
 kh_status alloc_slots(kh_table* t, uint64_t cap, KhSlots& s) {
-  s.keys = nullptr; s.vals = nullptr; s.info = nullptr; s.cap = 0;
-  hipError_t e = pool_alloc(t->device, std::max<uint64_t>(cap, 8) * 8, reinterpret_cast<void**>(&s.keys));
-  if (e == hipSuccess) e = pool_alloc(t->device, std::max<uint64_t>(cap, 8) * 4, reinterpret_cast<void**>(&s.vals));
-  if (e == hipSuccess) e = pool_alloc(t->device, cap + 256, reinterpret_cast<void**>(&s.info));
-  if (e != hipSuccess) { free_slots(t, s); return fail(t, KH_ERR_NOMEM, std::string("table allocation: ") + hipGetErrorString(e)); }
+  s = kNoSlots;
+  hipError_t e = pool_alloc(t->device, std::max<uint64_t>(cap, 16) * sizeof(KhSlot), reinterpret_cast<void**>(&s.s));
+  if (e != hipSuccess) { s = kNoSlots; return fail(t, KH_ERR_NOMEM, std::string("table allocation: ") + hipGetErrorString(e)); }
   s.cap = cap;
   return KH_OK;
 }
-// a destination buffer of capacity `cap` with every slot marked empty
+kh_status fill_empty(kh_table* t, KhSlots s) {
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((s.cap + 255) / 256, 256 * 16);
+  if (t->kind == KHK_RH) hipLaunchKernelGGL((k_fill_empty<KHK_RH>), dim3(grid), dim3(256), 0, t->stream, s);
+  else hipLaunchKernelGGL((k_fill_empty<KHK_LP>), dim3(grid), dim3(256), 0, t->stream, s);
+  HIPCHK(hipGetLastError());
+  return KH_OK;
+}
+// a destination buffer of capacity `cap`.  It is NOT cleared: a re-layout writes every slot of its destination, occupied or
+// empty, exactly once (the slices of the chunk workgroups tile the circular table), so clearing 16 B x capacity first
+// would only add a 2 GB memset per build of a 2^27-bucket table
 kh_status fresh_slots(kh_table* t, uint64_t cap, KhSlots& s) {
-  if (t->spare.cap == cap && t->spare.keys) { s = t->spare; t->spare = KhSlots{nullptr, nullptr, nullptr, 0}; }
+  if (t->spare.cap == cap && t->spare.s) { s = t->spare; t->spare = kNoSlots; }
   else {
     kh_status st = alloc_slots(t, cap, s);
     if (st != KH_OK) return st;
   }
-  HIPCHK(hipMemsetAsync(s.info, empty_byte(t->kind), cap + 256, t->stream));
+  if (g_poison) {
+    hipLaunchKernelGGL(k_poison, dim3((uint32_t)std::min<uint64_t>((cap + 255) / 256, 4096)), dim3(256), 0, t->stream, s);
+    HIPCHK(hipGetLastError());
+  }
   return KH_OK;
 }
 void retire_slots(kh_table* t, KhSlots& s) {   // keep one spare buffer for ping-pong rebuilds
-  if (!s.keys) return;
-  if (t->spare.keys) { hipStreamSynchronize(t->stream); free_slots(t, t->spare); }
+  if (!s.s) return;
+  if (t->spare.s) { hipStreamSynchronize(t->stream); free_slots(t, t->spare); }
   t->spare = s;
-  s = KhSlots{nullptr, nullptr, nullptr, 0};
+  s = kNoSlots;
 }
 
 // ---- profiling -----------------------------------------------------------------------------------
@@ -306,7 +315,7 @@ struct PreCount { uint16_t* homecnt; long long* sumA; long long* sumN; };   // c
 const bool g_disable_fused_rebuild = getenv("KH_DISABLE_FUSED_BUILD") != nullptr || getenv("KH_DISABLE_FUSED_REBUILD") != nullptr;   // test hooks
 
 kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint32_t* cv, const uint64_t* noff,
-                  const uint32_t* ncnt, uint32_t PB, const uint32_t* erased, uint64_t total_after, const PreCount* pre = nullptr) {
+                  const uint32_t* ncnt, uint32_t PB, bool drop_marked, uint64_t total_after, const PreCount* pre = nullptr) {
   if (total_after > new_cap)
     return fail(t, KH_ERR_FULL, "table would hold more elements than buckets (no slot to insert into)");
   KhSlots nw;
@@ -340,7 +349,7 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
     F.maxidx = maxidx; F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
     F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);
     F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);
-    F.R.Old = t->cur; F.R.erased_bits = erased; F.R.New = nw; F.R.ck = ck; F.R.cv = cv; F.R.noff = noff; F.R.ncnt = ncnt; F.R.PB = PB;
+    F.R.Old = t->cur; F.R.drop_marked = drop_marked ? 1 : 0; F.R.New = nw; F.R.ck = ck; F.R.cv = cv; F.R.noff = noff; F.R.ncnt = ncnt; F.R.PB = PB;
     if (from_empty) F.R.Old.cap = 0;     // nothing to carry over: the source scan is skipped
     F.R.seed = t->seed; F.R.flags = F.flags;
     { Launch L(t, "k_rebuild_fused");
@@ -353,7 +362,7 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
       HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
       KhRebuildParams T0;
       memset(&T0, 0, sizeof(T0));
-      T0.Old = KhSlots{nullptr, nullptr, nullptr, 0}; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0;
+      T0.Old = kNoSlots; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0;
       T0.PB = log2u(new_cap >> KH_LB);       // the parked list is chunk 0's own: one partition per chunk
       T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
       KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
@@ -390,7 +399,7 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
   TAKE(flags, uint32_t, KH_NFLAGS);
   HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
   KhRebuildParams P;
-  P.Old = t->cur; P.erased_bits = erased; P.New = nw; P.ck = ck; P.cv = cv; P.noff = noff; P.ncnt = ncnt; P.PB = PB;
+  P.Old = t->cur; P.drop_marked = drop_marked ? 1 : 0; P.New = nw; P.ck = ck; P.cv = cv; P.noff = noff; P.ncnt = ncnt; P.PB = PB;
   if (t->lsize == 0) P.Old.cap = 0;   // nothing to carry over: the chunk kernels skip the source scan
   P.seed = t->seed; P.homecnt = homecnt; P.sumA = sumA; P.sumN = sumN; P.xcarry = xcarry; P.flags = flags;
   if (!pre) { Launch L(t, "k_chunk_count");
@@ -441,7 +450,7 @@ kh_status do_rehash(kh_table* t, uint64_t b) {
     return fail(t, KH_ERR_FULL, "ERROR: did not find any place to insert.  should not have happend (hashmap_linearprobe.hpp:408)");
   }
   { kh_status ps = arena_prepare(t, ws_rebuild(n)); if (ps != KH_OK) return ps; }
-  kh_status st = rebuild(t, n, nullptr, nullptr, nullptr, nullptr, 0, nullptr, t->lsize);
+  kh_status st = rebuild(t, n, nullptr, nullptr, nullptr, nullptr, 0, false, t->lsize);
   arena_consolidate(t);
   return st;
 }
@@ -627,7 +636,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
       HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
       KhRebuildParams T0;
       memset(&T0, 0, sizeof(T0));
-      T0.Old = KhSlots{nullptr, nullptr, nullptr, 0}; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
+      T0.Old = kNoSlots; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
       T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
       KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
     }
@@ -710,7 +719,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
       HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
       KhRebuildParams T0;
       memset(&T0, 0, sizeof(T0));
-      T0.Old = KhSlots{nullptr, nullptr, nullptr, 0}; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
+      T0.Old = kNoSlots; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
       T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
       KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
     }
@@ -789,7 +798,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
       }
     }
     const bool pre_ok = fuse && new_cap == cap_u && !reinterpret_cast<const uint32_t*>(t->hpin + 2)[KH_FLAG_FUSE_INVALID];
-    st = rebuild(t, new_cap, ck, cv, lo, lc, PB, nullptr, t->lsize + dnew, pre_ok ? &pre : nullptr);
+    st = rebuild(t, new_cap, ck, cv, lo, lc, PB, false, t->lsize + dnew, pre_ok ? &pre : nullptr);
     if (st != KH_OK) return st;
     t->lsize += dnew;
   }
@@ -858,6 +867,108 @@ kh_status small_batch(kh_table* t, const char* kb, uint32_t kstride, const char*
   return KH_OK;
 }
 
+// ---- batches of middle size applied in place (Robin Hood; kh_kernels.h "Batches of middle size") --------------------------
+// Taken when no call of the batch can trigger a doubling (size + n <= max_load) and the batch is small against the table
+// (at most ~16 keys per region of 2048 slots): cost O(batch) instead of the O(table) re-layout.
+const bool g_disable_inplace = getenv("KH_DISABLE_INPLACE") != nullptr;      // test hook: force the re-layout
+inline bool inplace_ok(const kh_table* t, uint64_t n) {
+  return !g_disable_inplace && t->kind == KHK_RH && n > KH_SMALL_N && t->lsize > 0 && t->cur.cap >= 4 * (uint64_t)KH_L && n <= (t->cur.cap >> 7);
+}
+// the three passes over a list of (key, value) records / key array: regions, regions shifted by half, one lane
+template <int OP>
+kh_status inplace_passes(kh_table* t, const uint64_t* in_k, const uint32_t* in_v, uint64_t n_max, const unsigned long long* n_dev,
+                         unsigned long long** counters_out, uint32_t** flags_out) {
+  const uint32_t regions = (uint32_t)(t->cur.cap >> KH_LB);
+  uint32_t* cnt; ulonglong2 *bins, *defer1, *defer2; unsigned long long* c; uint32_t* flags;
+  TAKE(cnt, uint32_t, 2 * (size_t)regions);
+  TAKE(bins, ulonglong2, (size_t)regions * KH_IP_CAP);
+  TAKE(defer1, ulonglong2, n_max); TAKE(defer2, ulonglong2, n_max);
+  TAKE(c, unsigned long long, 4);            // [0] deferred by pass 1, [1] deferred by pass 2, [2] keys done
+  TAKE(flags, uint32_t, KH_NFLAGS);
+  HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)regions, t->stream));
+  HIPCHK(hipMemsetAsync(c, 0, 32, t->stream));
+  HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
+  KhInplaceParams P;
+  memset(&P, 0, sizeof(P));
+  P.T = t->cur; P.seed = t->seed; P.bins = bins; P.n_done = c + 2; P.flags = flags;
+  const uint32_t apply_grid = (regions + 63) / 64;
+  // pass 1: regions [r L, (r+1) L)
+  P.ofs = 0; P.in_k = in_k; P.in_v = in_v; P.n = n_max; P.n_dev = n_dev; P.cnt = cnt; P.defer = defer1; P.n_defer = c;
+  { Launch L(t, "k_ip_bin");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_bin<HASH>), dim3(grid_for(n_max, 256)), dim3(256), 0, t->stream, P)); }
+  { Launch L(t, "k_ip_apply");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_apply<HASH, OP>), dim3(apply_grid), dim3(64), 0, t->stream, P)); }
+  // pass 2: what crossed a boundary, regions shifted by half a region
+  P.ofs = KH_L / 2; P.in_k = nullptr; P.in_v = nullptr; P.in_rec = defer1; P.n = 0; P.n_dev = c; P.cnt = cnt + regions; P.defer = defer2; P.n_defer = c + 1;
+  { Launch L(t, "k_ip_bin");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_bin<HASH>), dim3(grid_for(std::max<uint64_t>(n_max / 16, 256), 256)), dim3(256), 0, t->stream, P)); }
+  { Launch L(t, "k_ip_apply");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_apply<HASH, OP>), dim3(apply_grid), dim3(64), 0, t->stream, P)); }
+  // pass 3: the rest, one lane
+  P.in_rec = defer2; P.n_dev = c + 1;
+  { Launch L(t, "k_ip_serial");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_serial<HASH, OP>), dim3(1), dim3(64), 0, t->stream, P)); }
+  HIPCHK(hipGetLastError());
+  *counters_out = c; *flags_out = flags;
+  return KH_OK;
+}
+
+kh_status insert_inplace(kh_table* t, const char* kb, uint32_t kstride, const char* vb, uint32_t vstride, uint64_t n, int mode, uint64_t* n_new_out) {
+  *n_new_out = 0;
+  // equal keys must meet: partition by a few hash bits into pieces of ~1024 records (one pass), fold duplicates in LDS and
+  // test membership against the table (k_dedup: updates / sums of EXISTING keys happen there); what comes out are the
+  // batch's distinct NEW keys
+  uint32_t PB = 0;
+  while (PB < 11 && (n >> PB) > 1024) ++PB;
+  ulonglong2 *tmp, *fin;
+  TAKE(tmp, ulonglong2, n); TAKE(fin, ulonglong2, n);
+  Partitioned R;
+  kh_status st = partition_batch(t, kb, kstride, vb, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R);
+  if (st != KH_OK) return st;
+  KhSrcSet S;
+  memset(&S, 0, sizeof(S));
+  S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off;
+  uint32_t* cnt_new; uint64_t* noff; unsigned long long* scal; uint32_t* dflags; uint64_t* gk; uint32_t* gv;
+  TAKE(cnt_new, uint32_t, R.nparts); TAKE(noff, uint64_t, R.nparts + 1); TAKE(scal, unsigned long long, 4); TAKE(dflags, uint32_t, KH_NFLAGS);
+  TAKE(gk, uint64_t, n); TAKE(gv, uint32_t, n);
+  HIPCHK(hipMemsetAsync(scal, 0, 32, t->stream));
+  HIPCHK(hipMemsetAsync(dflags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
+  KhDedupParams D;
+  memset(&D, 0, sizeof(D));
+  D.src = S;
+  D.nk = reinterpret_cast<uint64_t*>(R.spare); D.nv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(R.spare) + n * 8);
+  D.cnt_new = cnt_new; D.max_idx_plus1 = scal; D.count_cap = 0; D.PB = PB;
+  D.T = t->cur; D.seed = t->seed; D.table_empty = 0; D.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST; D.flags = dflags;
+  { Launch L(t, "k_dedup");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
+  { Launch L(t, "k_scan");
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, cnt_new, (uint64_t)R.nparts, noff); }
+  { Launch L(t, "k_gather_new");
+    hipLaunchKernelGGL(k_gather_new, dim3(R.nparts), dim3(256), 0, t->stream, S.merged_off, noff, D.nk, D.nv, gk, gv); }
+  unsigned long long* c; uint32_t* flags;
+  st = inplace_passes<KH_IP_INSERT>(t, gk, gv, n, reinterpret_cast<const unsigned long long*>(noff + R.nparts), &c, &flags);
+  if (st != KH_OK) return st;
+  if (mode == INS_UPDATE) {   // update(k,v): every key of the batch is in the table now; it takes the value of its LAST occurrence
+    D.mode = KH_DEDUP_LAST;
+    Launch L(t, "k_dedup_assign");
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D));
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(t->hpin, noff + R.nparts, 8, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipMemcpyAsync(t->hpin + 1, c, 24, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipMemcpyAsync(t->hpin + 4, flags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipMemcpyAsync(t->hpin + 8, dflags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  const uint64_t dnew = t->hpin[0], placed = t->hpin[3];
+  t->lsize += placed;
+  *n_new_out = placed;
+  if (reinterpret_cast<const uint32_t*>(t->hpin + 8)[KH_FLAG_INTERNAL]) return fail(t, KH_ERR_HIP, "internal: de-duplication set overflow");
+  if (placed != dnew || reinterpret_cast<const uint32_t*>(t->hpin + 4)[KH_FLAG_PROBE_OVERFLOW])
+    return fail(t, KH_ERR_PROBE_OVERFLOW, "Robin Hood probe distance would exceed 127 (7-bit info field, hashmap_robinhood.hpp:142-144,556); "
+                                          "the keys of the batch that fit were applied in place");
+  return KH_OK;
+}
+
 kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void* vals, uint32_t vstride, uint64_t n,
                     kh_mem where, int mode, uint64_t* n_inserted, bool tail_reserve = true) {
   if (n_inserted) *n_inserted = 0;
@@ -865,7 +976,9 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
   if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
   { const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n ? n : 1, n, n ? n - 1 : 0);
-    kh_status ps = arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
+    const bool ip = inplace_ok(t, n) && t->lsize + n <= t->max_load;      // in place: no re-layout workspace, bins instead
+    kh_status ps = ip ? arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 80 + (t->cur.cap >> KH_LB) * (size_t)(KH_IP_CAP * 16 + 8) + (size_t(2) << 20))
+                      : arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
     if (ps != KH_OK) return ps; }
   const char* kb = static_cast<const char*>(keys);
   const char* vb = static_cast<const char*>(vals);
@@ -901,6 +1014,12 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
     kb += (uint64_t)done * kstride;
     if (vb) vb += (uint64_t)done * vstride;
     n -= done;                      // > 0 only when a displacement chain would pass distance 127: the general path reports it
+  }
+  if (n > 0 && inplace_ok(t, n) && t->lsize + n <= t->max_load) {
+    uint64_t more = 0;
+    st = insert_inplace(t, kb, kstride, vb, vstride, n, mode, &more);
+    total_new += more;
+    n = 0;
   }
   if (n > 0) {
     uint64_t more = 0;
@@ -939,6 +1058,36 @@ kh_status compact(kh_table* t, const uint8_t* flags, const uint64_t* q, const ui
   return KH_OK;
 }
 
+// launches k_find<KIND, HASH, OUT> over n device-resident queries; *hits_dev (device, 8 B) receives the number of hits
+kh_status launch_find(kh_table* t, int out_mode, const uint64_t* q, uint64_t n, uint32_t* dvals, uint8_t* dfound, uint64_t* dkeys, uint8_t* dpairs,
+                      unsigned long long** hits_dev) {
+  const uint64_t ntiles = (n + KH_Q_TILE - 1) / KH_Q_TILE;
+  // control block: [0] hit count, [1] ticket, then one look-back granule per tile (compacted forms)
+  unsigned long long* ctl;
+  const size_t nctl = 2 + ((out_mode == KH_FIND_COMPACT || out_mode == KH_FIND_PAIRS) ? ntiles : 0);
+  TAKE(ctl, unsigned long long, nctl);
+  HIPCHK(hipMemsetAsync(ctl, 0, nctl * 8, t->stream));
+  KhFindParams F;
+  memset(&F, 0, sizeof(F));
+  F.T = t->cur; F.q = q; F.n = n; F.seed = t->seed;
+  F.out_vals = dvals; F.out_found = dfound; F.out_keys = dkeys; F.out_pairs16 = dpairs;
+  F.n_found = ctl; F.ticket = reinterpret_cast<uint32_t*>(ctl + 1); F.tile_state = ctl + 2;
+  int ncu = 256;
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, t->device);
+  const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, (uint64_t)ncu * 8));
+  const char* name = out_mode == KH_FIND_COUNT ? "k_count" : "k_find";
+  { Launch L(t, name);
+    switch (out_mode) {
+      case KH_FIND_PERQUERY: KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, KH_FIND_PERQUERY>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); break;
+      case KH_FIND_COMPACT: KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, KH_FIND_COMPACT>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); break;
+      case KH_FIND_PAIRS: KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, KH_FIND_PAIRS>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); break;
+      default: KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, KH_FIND_COUNT>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); break;
+    } }
+  HIPCHK(hipGetLastError());
+  if (hits_dev) *hits_dev = ctl;
+  return KH_OK;
+}
+
 kh_status do_find(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint32_t* out_vals, uint8_t* out_found,
                   uint64_t* out_ckeys, uint32_t* out_cvals, void* out_pairs, bool compacted, uint64_t* n_found) {
   if (n_found) *n_found = 0;
@@ -946,36 +1095,41 @@ kh_status do_find(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint3
   if (n == 0) return KH_OK;
   if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
-  { kh_status ps = arena_prepare(t, n * 40 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
+  { kh_status ps = arena_prepare(t, n * 40 + (n / KH_Q_TILE + 8) * 8 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
   const uint64_t* q;
   kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
   if (st != KH_OK) return st;
   const bool host = where == KH_MEM_HOST;
-  uint32_t* dv = out_vals; uint8_t* df = out_found;
-  if (host || compacted || !dv) TAKE(dv, uint32_t, n);
-  if (host || compacted || !df) TAKE(df, uint8_t, n);
-  { Launch L(t, "k_find");
-    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH>), dim3(grid_for(n, 256)), dim3(256), 0, t->stream, t->cur, q, n, t->seed, dv, df)); }
-  HIPCHK(hipGetLastError());
+  unsigned long long* hits_dev = nullptr;
   uint64_t hits = 0;
   if (!compacted) {
-    if (n_found) { st = compact(t, df, nullptr, nullptr, n, nullptr, nullptr, nullptr, &hits); if (st != KH_OK) return st; }
+    uint32_t* dv = out_vals; uint8_t* df = out_found;
+    if (host && dv) TAKE(dv, uint32_t, n);
+    if (host || !df) TAKE(df, uint8_t, n);
+    st = launch_find(t, KH_FIND_PERQUERY, q, n, dv, df, nullptr, nullptr, &hits_dev);
+    if (st != KH_OK) return st;
+    HIPCHK(hipMemcpyAsync(t->hpin, hits_dev, 8, hipMemcpyDeviceToHost, t->stream));
     if (host) {
       // values of misses stay untouched in the caller's buffer: copy through a flag-selective host loop
-      std::vector<uint32_t> hv(n); std::vector<uint8_t> hf(n);
-      HIPCHK(hipMemcpyAsync(hv.data(), dv, n * 4, hipMemcpyDeviceToHost, t->stream));
+      std::vector<uint32_t> hv(out_vals ? n : 0); std::vector<uint8_t> hf(n);
+      if (out_vals) HIPCHK(hipMemcpyAsync(hv.data(), dv, n * 4, hipMemcpyDeviceToHost, t->stream));
       HIPCHK(hipMemcpyAsync(hf.data(), df, n, hipMemcpyDeviceToHost, t->stream));
       HIPCHK(hipStreamSynchronize(t->stream));
       for (uint64_t i = 0; i < n; ++i) { if (out_found) out_found[i] = hf[i]; if (hf[i] && out_vals) out_vals[i] = hv[i]; }
-    }
+    } else if (n_found) HIPCHK(hipStreamSynchronize(t->stream));
+    hits = t->hpin[0];
   } else {
     uint64_t* ck = out_ckeys; uint32_t* cv = out_cvals; uint8_t* cp = static_cast<uint8_t*>(out_pairs);
     if (host) {
       if (out_pairs) TAKE(cp, uint8_t, n * 16);
       else { TAKE(ck, uint64_t, n); TAKE(cv, uint32_t, n); }
     }
-    st = compact(t, df, q, dv, n, out_pairs ? nullptr : ck, out_pairs ? nullptr : cv, out_pairs ? cp : nullptr, &hits);
+    st = launch_find(t, out_pairs ? KH_FIND_PAIRS : KH_FIND_COMPACT, q, n, out_pairs ? nullptr : cv, nullptr, out_pairs ? nullptr : ck,
+                     out_pairs ? cp : nullptr, &hits_dev);
     if (st != KH_OK) return st;
+    HIPCHK(hipMemcpyAsync(t->hpin, hits_dev, 8, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    hits = t->hpin[0];
     if (host && hits) {
       if (out_pairs) HIPCHK(hipMemcpyAsync(out_pairs, cp, hits * 16, hipMemcpyDeviceToHost, t->stream));
       else {
@@ -997,7 +1151,9 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
   if (n == 0) return KH_OK;
   if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
-  { kh_status ps = arena_prepare(t, n * 8 + t->cur.cap / 8 + ws_rebuild(t->cur.cap) + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
+  { kh_status ps = inplace_ok(t, n) ? arena_prepare(t, n * 40 + (t->cur.cap >> KH_LB) * (size_t)(KH_IP_CAP * 16 + 8) + (size_t(2) << 20))
+                                    : arena_prepare(t, n * 8 + ws_rebuild(t->cur.cap) + (size_t(1) << 20));
+    if (ps != KH_OK) return ps; }
   const uint64_t* q;
   kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
   if (st != KH_OK) return st;
@@ -1009,23 +1165,32 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
     *n_erased = ne;
     return KH_OK;
   }
-  unsigned long long* cnt; uint32_t* bits = nullptr;
+  if (inplace_ok(t, n)) {       // backward-shift deletes in place, one lane per region of the table
+    unsigned long long* c; uint32_t* flags;
+    st = inplace_passes<KH_IP_ERASE>(t, q, nullptr, n, nullptr, &c, &flags);
+    if (st != KH_OK) return st;
+    HIPCHK(hipMemcpyAsync(t->hpin, c + 2, 8, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    t->lsize -= t->hpin[0];
+    *n_erased = t->hpin[0];
+    return KH_OK;
+  }
+  unsigned long long* cnt;
   TAKE(cnt, unsigned long long, 1);
   HIPCHK(hipMemsetAsync(cnt, 0, 8, t->stream));
-  if (t->kind == KHK_RH) {
-    const uint64_t words = (t->cur.cap + 31) / 32;
-    TAKE(bits, uint32_t, words);
-    HIPCHK(hipMemsetAsync(bits, 0, words * 4, t->stream));
-  }
   { Launch L(t, "k_erase_mark");
-    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_erase_mark<KIND, HASH>), dim3(grid_for(n, 256)), dim3(256), 0, t->stream, t->cur, q, n, t->seed, bits, cnt)); }
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_erase_mark<KIND, HASH>), dim3(grid_for(n, KH_Q_THREADS)), dim3(KH_Q_THREADS), 0, t->stream, t->cur, q, n, t->seed, cnt)); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(t->hpin, cnt, 8, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   const uint64_t ne = t->hpin[0];
   if (ne && t->kind == KHK_RH) {
-    st = rebuild(t, t->cur.cap, nullptr, nullptr, nullptr, nullptr, 0, bits, t->lsize - ne);
-    if (st != KH_OK) return st;
+    st = rebuild(t, t->cur.cap, nullptr, nullptr, nullptr, nullptr, 0, true, t->lsize - ne);
+    if (st != KH_OK) {        // the table keeps its elements: take the marks back
+      hipLaunchKernelGGL(k_clear_marks, dim3(grid_for(t->cur.cap, 256)), dim3(256), 0, t->stream, t->cur);
+      hipStreamSynchronize(t->stream);
+      return st;
+    }
   }
   t->lsize -= ne;
   *n_erased = ne;
@@ -1064,14 +1229,14 @@ kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t v
   kh_table* t = new kh_table();
   t->kind = (int)kind; t->hash = (int)hash; t->device = device; t->seed = seed; t->stream = nullptr;
   t->min_lf = min_lf; t->max_lf = max_lf; t->lsize = 0;
-  t->cur = KhSlots{nullptr, nullptr, nullptr, 0}; t->spare = t->cur;
+  t->cur = kNoSlots; t->spare = t->cur;
   t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false;
   memset(&t->ins, 0, sizeof(t->ins));
   const uint64_t cap = next_pow2(capacity);
   if (alloc_slots(t, cap, t->cur) != KH_OK) { delete t; return KH_ERR_NOMEM; }
   t->hpin = pinned_get();
   if (!t->hpin) { free_slots(t, t->cur); delete t; return KH_ERR_NOMEM; }
-  if (hipMemset(t->cur.info, empty_byte(t->kind), cap + 256) != hipSuccess) { free_slots(t, t->cur); pinned_put(t->hpin); delete t; return KH_ERR_HIP; }
+  if (fill_empty(t, t->cur) != KH_OK || hipStreamSynchronize(t->stream) != hipSuccess) { free_slots(t, t->cur); pinned_put(t->hpin); delete t; return KH_ERR_HIP; }
   t->min_load = threshold(cap, min_lf);
   t->max_load = threshold(cap, max_lf);
   *out = t;
@@ -1122,7 +1287,7 @@ kh_status kh_clear(kh_table* t) {
   if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
   t->lsize = 0;
-  HIPCHK(hipMemsetAsync(t->cur.info, empty_byte(t->kind), t->cur.cap + 256, t->stream));
+  { kh_status fs = fill_empty(t, t->cur); if (fs != KH_OK) return fs; }
   HIPCHK(hipStreamSynchronize(t->stream));
   return KH_OK;
 }
@@ -1248,9 +1413,8 @@ kh_status kh_count(kh_table* t, const void* keys, uint64_t n, kh_mem where, uint
   if (st != KH_OK) return st;
   uint8_t* d = out01;
   if (where == KH_MEM_HOST) TAKE(d, uint8_t, n);
-  { Launch L(t, "k_count");
-    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_count<KIND, HASH>), dim3(grid_for(n, 256)), dim3(256), 0, t->stream, t->cur, q, n, t->seed, d)); }
-  HIPCHK(hipGetLastError());
+  st = launch_find(t, KH_FIND_COUNT, q, n, nullptr, d, nullptr, nullptr, nullptr);
+  if (st != KH_OK) return st;
   if (where == KH_MEM_HOST) {
     HIPCHK(hipMemcpyAsync(out01, d, n, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
@@ -1297,19 +1461,31 @@ kh_status kh_erase_one(kh_table* t, uint64_t key, uint64_t* n_erased) {
   return st;
 }
 
+}  // extern "C"
+namespace {
+// SoA view of the current table in the workspace (any of keys / vals / info / flags may be null)
+kh_status unpack(kh_table* t, uint64_t* k, uint32_t* v, uint8_t* info, uint8_t* flags) {
+  const uint64_t cap = t->cur.cap;
+  Launch L(t, "k_unpack_slots");
+  if (t->kind == KHK_RH) hipLaunchKernelGGL((k_unpack_slots<KHK_RH>), dim3(grid_for(cap, 256)), dim3(256), 0, t->stream, t->cur.s, cap, k, v, info, flags);
+  else hipLaunchKernelGGL((k_unpack_slots<KHK_LP>), dim3(grid_for(cap, 256)), dim3(256), 0, t->stream, t->cur.s, cap, k, v, info, flags);
+  HIPCHK(hipGetLastError());
+  return KH_OK;
+}
+}  // namespace
+extern "C" {
 kh_status kh_to_vector(kh_table* t, uint64_t* keys_host, uint32_t* vals_host, uint64_t* n_out) {
   if (!t) return KH_ERR_INVALID;
   if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
-  { kh_status ps = arena_prepare(t, t->cur.cap * 14 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
+  { kh_status ps = arena_prepare(t, t->cur.cap * 26 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
   const uint64_t cap = t->cur.cap;
-  uint8_t* flags; uint64_t* ck; uint32_t* cv;
-  TAKE(flags, uint8_t, cap); TAKE(ck, uint64_t, cap); TAKE(cv, uint32_t, cap);
-  { Launch L(t, "k_occupied_flags");
-    if (t->kind == KHK_RH) hipLaunchKernelGGL((k_occupied_flags<KHK_RH>), dim3(grid_for(cap, 256)), dim3(256), 0, t->stream, t->cur.info, cap, flags);
-    else hipLaunchKernelGGL((k_occupied_flags<KHK_LP>), dim3(grid_for(cap, 256)), dim3(256), 0, t->stream, t->cur.info, cap, flags); }
+  uint8_t* flags; uint64_t *sk, *ck; uint32_t *sv, *cv;
+  TAKE(flags, uint8_t, cap); TAKE(sk, uint64_t, cap); TAKE(sv, uint32_t, cap); TAKE(ck, uint64_t, cap); TAKE(cv, uint32_t, cap);
+  kh_status st = unpack(t, sk, sv, nullptr, flags);
+  if (st != KH_OK) return st;
   uint64_t m = 0;
-  kh_status st = compact(t, flags, t->cur.keys, t->cur.vals, cap, ck, cv, nullptr, &m);
+  st = compact(t, flags, sk, sv, cap, ck, cv, nullptr, &m);
   if (st != KH_OK) return st;
   if (m && keys_host) HIPCHK(hipMemcpyAsync(keys_host, ck, m * 8, hipMemcpyDeviceToHost, t->stream));
   if (m && vals_host) HIPCHK(hipMemcpyAsync(vals_host, cv, m * 4, hipMemcpyDeviceToHost, t->stream));
@@ -1320,16 +1496,28 @@ kh_status kh_to_vector(kh_table* t, uint64_t* keys_host, uint32_t* vals_host, ui
 }
 kh_status kh_export_info(kh_table* t, uint8_t* out_host) {
   if (!t || !out_host) return KH_ERR_INVALID;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
-  HIPCHK(hipMemcpyAsync(out_host, t->cur.info, t->cur.cap, hipMemcpyDeviceToHost, t->stream));
+  { kh_status ps = arena_prepare(t, t->cur.cap + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
+  uint8_t* info;
+  TAKE(info, uint8_t, t->cur.cap);
+  kh_status st = unpack(t, nullptr, nullptr, info, nullptr);
+  if (st != KH_OK) return st;
+  HIPCHK(hipMemcpyAsync(out_host, info, t->cur.cap, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return KH_OK;
 }
 kh_status kh_export_slots(kh_table* t, uint64_t* keys_host, uint32_t* vals_host) {
   if (!t) return KH_ERR_INVALID;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
-  if (keys_host) HIPCHK(hipMemcpyAsync(keys_host, t->cur.keys, t->cur.cap * 8, hipMemcpyDeviceToHost, t->stream));
-  if (vals_host) HIPCHK(hipMemcpyAsync(vals_host, t->cur.vals, t->cur.cap * 4, hipMemcpyDeviceToHost, t->stream));
+  { kh_status ps = arena_prepare(t, t->cur.cap * 12 + (size_t(1) << 20)); if (ps != KH_OK) return ps; }
+  uint64_t* sk; uint32_t* sv;
+  TAKE(sk, uint64_t, t->cur.cap); TAKE(sv, uint32_t, t->cur.cap);
+  kh_status st = unpack(t, sk, sv, nullptr, nullptr);
+  if (st != KH_OK) return st;
+  if (keys_host) HIPCHK(hipMemcpyAsync(keys_host, sk, t->cur.cap * 8, hipMemcpyDeviceToHost, t->stream));
+  if (vals_host) HIPCHK(hipMemcpyAsync(vals_host, sv, t->cur.cap * 4, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return KH_OK;
 }
@@ -1344,7 +1532,7 @@ kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]) {
   TAKE(d, unsigned long long, 128);
   HIPCHK(hipMemsetAsync(d, 0, 128 * 8, t->stream));
   { Launch L(t, "k_disp_hist");
-    hipLaunchKernelGGL(k_disp_hist, dim3(grid_for(t->cur.cap, 256, 1024)), dim3(256), 0, t->stream, t->cur.info, t->cur.cap, d); }
+    hipLaunchKernelGGL(k_disp_hist, dim3(grid_for(t->cur.cap, 256, 1024)), dim3(256), 0, t->stream, t->cur.s, t->cur.cap, d); }
   HIPCHK(hipMemcpyAsync(out, d, 128 * 8, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return KH_OK;

@@ -823,3 +823,88 @@ def test_calls_inside_a_streamed_insert_are_refused():
     o = np.argsort(k)
     assert np.array_equal(kk, k[o]) and np.array_equal(vv, v[o])
     g.close()
+
+
+@pytest.mark.parametrize("hname,hid", [("murmur3avx64", 1), ("farm", 3)])
+def test_mid_size_batches_are_applied_in_place(oracle, hname, hid):
+    """10^2..10^6 keys into a large Robin Hood table cost O(batch): the table is cut into regions owned by one
+    lane each, keys whose displacement chain / backward shift would leave the region are deferred to a pass with shifted
+    regions, the rest to a single lane (hashmap_robinhood.hpp:522-624,1294-1356).  Bit-exact info array after every step."""
+    cap = 1 << 20                                              # 512 regions; in place for 17..8192 keys
+    base = W.distinct_u64(600_000, seed=77)
+    bv = np.arange(len(base), dtype=np.uint32)
+    g = kh.hashmap_robinhood_doubling(cap, 0.35, 0.8, hash=hname, seed=43)
+    o = oracle.OracleTable(0, cap, 0.35, 0.8, hid, 43)
+    assert g.insert(dev(base), dev(bv)) == o.insert(base, bv)
+    fresh = W.distinct_u64(40_000, seed=78)
+    pos = 0
+    rng = np.random.default_rng(5)
+    g.profile_enable(True)
+    for n in (17, 100, 1000, 8000, 8192):
+        new = fresh[pos:pos + n]; pos += n
+        # new keys, duplicates of them, and keys the table already holds, shuffled
+        k = np.concatenate([new, new[: n // 3], base[rng.integers(0, len(base), n // 4)]])[:n]
+        k = k[rng.permutation(len(k))]
+        v = rng.integers(0, 1 << 32, len(k), dtype=np.uint64).astype(np.uint32)
+        assert g.insert(dev(k), dev(v)) == o.insert(k, v)
+        check_state(g, o, 0)
+    assert g.capacity() == cap
+    prof = g.profile()
+    assert prof["k_ip_apply"][0] == 10 and "k_rebuild_fused" not in prof and "k_insert_fused" not in prof, prof
+    # update: existing keys take the last value, new ones are inserted
+    k = np.concatenate([fresh[pos:pos + 3000], base[:2000], fresh[pos:pos + 500]]); pos += 3000
+    v = np.arange(len(k), dtype=np.uint32) + np.uint32(9)
+    g.update(dev(k), dev(v))
+    for kk, vv in zip(k.tolist(), v.tolist()):
+        o.update_one(kk, vv)
+    check_state(g, o, 0)
+    # erase in place: hits, misses and repeated keys
+    for n in (50, 5000, 8192):
+        e = np.concatenate([base[rng.integers(0, len(base), n - n // 5)], W.distinct_u64(n // 5, seed=1000 + n)])
+        assert g.erase(dev(e)) == o.erase(e)
+        check_state(g, o, 0)
+    assert g.profile()["k_ip_apply"][0] == 18
+    check_queries(g, o, np.concatenate([base[:3000], fresh[:3000], W.distinct_u64(1000, seed=4)]))
+    # counting insert (std::plus) in place
+    k = np.concatenate([fresh[pos:pos + 2000], fresh[pos:pos + 2000], base[:1000]])
+    g.insert_reduce_plus(dev(k))
+    sk, sv = g.sorted_items(); ok, ov = o.sorted_items()
+    uk, cnt = np.unique(k, return_counts=True)
+    exp = dict(zip(ok.tolist(), ov.tolist()))
+    for a, c in zip(uk.tolist(), cnt.tolist()):
+        exp[a] = (exp.get(a, 0) + c) & 0xFFFFFFFF
+    assert np.array_equal(sk, np.array(sorted(exp), dtype=np.uint64))
+    assert np.array_equal(sv, np.array([exp[a] for a in sorted(exp)], dtype=np.uint32))
+    g.close()
+
+
+def test_mid_size_in_place_region_boundaries(oracle):
+    """identity hash, crafted homes: chains that cross a region boundary (pass 2), chains that cross a regular AND a shifted
+    boundary (a run of 1100 occupied slots over 1024 and 2048: pass 3, the single lane), and more keys in one region than a
+    bin holds"""
+    cap = 1 << 16                                              # 32 regions of 2048 slots; in place for 17..512 keys
+    run = np.arange(1000, 2100, dtype=np.uint64)               # every slot of [1000, 2100) holds an element at its home
+    sparse = np.arange(4096, 60_000, 7, dtype=np.uint64)
+    keys = np.concatenate([run, sparse])
+    vals = np.arange(len(keys), dtype=np.uint32)
+    g = kh.hashmap_robinhood_doubling(cap, 0.35, 0.8, hash="identity")
+    o = oracle.OracleTable(0, cap, 0.35, 0.8, 0, 43)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals)
+    hi = np.uint64(1) << np.uint64(32)
+    new = np.concatenate([
+        np.uint64(1010) + hi * np.arange(1, 4, dtype=np.uint64),            # home inside the long run: chain ends behind 2100
+        np.uint64(2040) + hi * np.arange(1, 6, dtype=np.uint64),            # home just before a regular boundary
+        np.uint64(1020) + hi * np.arange(5, 8, dtype=np.uint64),            # just before a shifted boundary
+        np.uint64(30_000) + np.uint64(7) * np.arange(40, dtype=np.uint64) + hi,   # 40 keys in one region (bin capacity 16)
+        np.uint64(65_530) + hi * np.arange(1, 9, dtype=np.uint64),          # runs over the end of the table into slot 0
+    ])
+    nv = np.arange(len(new), dtype=np.uint32) + np.uint32(1000)
+    g.profile_enable(True)
+    assert g.insert(dev(new), dev(nv)) == o.insert(new, nv) == len(new)
+    assert "k_ip_serial" in g.profile() and g.capacity() == cap
+    check_state(g, o, 0)
+    check_queries(g, o, np.concatenate([new, run[:50], np.uint64(1010) + hi * np.arange(20, 25, dtype=np.uint64)]))
+    e = np.concatenate([run[5:40], new[:8], new[-8:], np.uint64(30_000) + np.uint64(7) * np.arange(40, dtype=np.uint64) + hi])
+    assert g.erase(dev(e)) == o.erase(e)
+    check_state(g, o, 0)
+    g.close()
