@@ -112,8 +112,9 @@ __global__ void k_hash_batch(const uint64_t* __restrict__ keys, uint64_t n, uint
 // been started: the wait is bounded by their run time, not by the dispatcher's order.
 // ---------------------------------------------------------------------------------------------
 #define KH_Q_THREADS 256
-#define KH_Q_ITEMS 8
-#define KH_Q_TILE (KH_Q_THREADS * KH_Q_ITEMS)
+#define KH_Q_ITEMS 4
+#define KH_Q_NB 4                // batches of KH_Q_ITEMS queries per lane and tile (one look-back per tile)
+#define KH_Q_TILE (KH_Q_THREADS * KH_Q_ITEMS * KH_Q_NB)
 #define KH_LB_AGG (1ull << 62)
 #define KH_LB_PRE (2ull << 62)
 #define KH_LB_VAL ((1ull << 62) - 1ull)
@@ -128,36 +129,67 @@ struct KhFindParams {
   unsigned long long* n_found;                     // zero at launch: total hits
 };
 
-// probes the KH_Q_ITEMS queries of this lane; returns the bit mask of hits, vals[j] of the hits
+// probes the KH_Q_ITEMS queries of this lane; returns the bit mask of hits, vals[j] of the hits.
+// A probe reads the table one 64-byte SECTOR (KH_Q_W = 4 aligned slots) at a time: the four 16-byte loads of a sector are
+// in flight together, so a chain of d slots costs ceil((d + offset) / 4) dependent memory round trips instead of d -- the
+// rounds a wave spends on the longest chain among its 256 queries (12-15 slots at load 0.8) drop from ~14 to ~4.
+#define KH_Q_W 4
 template <int KIND, int HASH>
 __device__ __forceinline__ uint32_t kh_probe_items(const KhSlots& T, const uint64_t (&key)[KH_Q_ITEMS], uint32_t valid, uint64_t seed,
                                                    uint32_t (&val)[KH_Q_ITEMS]) {
   const uint64_t mask = T.cap - 1;
-  uint64_t pos[KH_Q_ITEMS];
-  uint4 w[KH_Q_ITEMS];
+  uint32_t hit = 0;
+  if (T.cap < KH_Q_W) {                                // tables of 1 or 2 buckets: slot by slot
 #pragma unroll
-  for (int j = 0; j < KH_Q_ITEMS; ++j) pos[j] = kh_hash64<HASH>(key[j], seed) & mask;
+    for (int j = 0; j < KH_Q_ITEMS; ++j)
+      if ((valid >> j) & 1u) { if (kh_find_pos<KIND>(T.s, mask, kh_hash64<HASH>(key[j], seed) & mask, key[j], &val[j]) != KH_NONE) hit |= 1u << j; }
+    return hit;
+  }
+  uint64_t base[KH_Q_ITEMS];                           // first slot of the sector being looked at
+  uint32_t first[KH_Q_ITEMS];                          // slots of that sector in front of the home bucket (first sector only)
+  uint32_t dist[KH_Q_ITEMS];                           // probe distance of slot base + first
+  uint4 w[KH_Q_ITEMS][KH_Q_W];
 #pragma unroll
-  for (int j = 0; j < KH_Q_ITEMS; ++j) if ((valid >> j) & 1u) w[j] = kh_slot_ld(T.s + pos[j]);
-  uint32_t active = valid, hit = 0;
-  uint32_t dist = 0;                                // every unresolved query of the lane is at the same step
+  for (int j = 0; j < KH_Q_ITEMS; ++j) {
+    const uint64_t home = kh_hash64<HASH>(key[j], seed) & mask;
+    base[j] = home & ~(uint64_t)(KH_Q_W - 1); first[j] = (uint32_t)(home & (KH_Q_W - 1)); dist[j] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < KH_Q_ITEMS; ++j)
+    if ((valid >> j) & 1u) {
+#pragma unroll
+      for (int s = 0; s < KH_Q_W; ++s) w[j][s] = kh_slot_ld(T.s + base[j] + s);
+    }
+  uint32_t active = valid;
+  const uint64_t max_steps = KIND == KHK_RH ? 128u : T.cap;
   while (active) {
 #pragma unroll
     for (int j = 0; j < KH_Q_ITEMS; ++j) {
-      if (!((active >> j) & 1u)) continue;
-      const uint32_t b = w[j].w & 0xFFu;
-      if (KIND == KHK_RH) {
-        if (0x80u + dist > b) active &= ~(1u << j);                                               // richer resident or empty: absent
-        else if (0x80u + dist == b && kh_slot_key(w[j]) == key[j]) { hit |= 1u << j; val[j] = w[j].z; active &= ~(1u << j); }
-      } else {
-        if (b == 0x40u) active &= ~(1u << j);
-        else if (b < 0x40u && kh_slot_key(w[j]) == key[j]) { hit |= 1u << j; val[j] = w[j].z; active &= ~(1u << j); }
+#pragma unroll
+      for (int s = 0; s < KH_Q_W; ++s) {
+        if (((active >> j) & 1u) && (uint32_t)s >= first[j]) {
+          const uint32_t b = w[j][s].w & 0xFFu;
+          if (KIND == KHK_RH) {
+            const uint32_t reprobe = 0x80u + dist[j] + (uint32_t)s - first[j];
+            if (reprobe > b || reprobe > 0xFFu) active &= ~(1u << j);                               // richer resident or empty: absent
+            else if (reprobe == b && kh_slot_key(w[j][s]) == key[j]) { hit |= 1u << j; val[j] = w[j][s].z; active &= ~(1u << j); }
+          } else {
+            if (b == 0x40u) active &= ~(1u << j);
+            else if (b < 0x40u && kh_slot_key(w[j][s]) == key[j]) { hit |= 1u << j; val[j] = w[j][s].z; active &= ~(1u << j); }
+          }
+        }
       }
     }
-    ++dist;
-    if (KIND == KHK_RH ? dist >= 128u : (uint64_t)dist > mask) break;
 #pragma unroll
-    for (int j = 0; j < KH_Q_ITEMS; ++j) if ((active >> j) & 1u) { pos[j] = (pos[j] + 1) & mask; w[j] = kh_slot_ld(T.s + pos[j]); }
+    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+      if ((active >> j) & 1u) {
+        dist[j] += KH_Q_W - first[j]; first[j] = 0;
+        if ((uint64_t)dist[j] >= max_steps) { active &= ~(1u << j); continue; }
+        base[j] = (base[j] + KH_Q_W) & mask;
+#pragma unroll
+        for (int s = 0; s < KH_Q_W; ++s) w[j][s] = kh_slot_ld(T.s + base[j] + s);
+      }
+    }
   }
   return hit;
 }
@@ -165,61 +197,77 @@ __device__ __forceinline__ uint32_t kh_probe_items(const KhSlots& T, const uint6
 template <int KIND, int HASH, int OUT>
 __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
   __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_wcnt[KH_Q_ITEMS][KH_Q_THREADS / 64];
+  __shared__ uint32_t s_wcnt[KH_Q_NB * KH_Q_ITEMS][KH_Q_THREADS / 64];
   __shared__ unsigned long long s_prefix;
+  __shared__ uint32_t s_val[(OUT == KH_FIND_COMPACT || OUT == KH_FIND_PAIRS) ? KH_Q_TILE : 1];      // values of the tile's hits (16 KB)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t ntiles = (uint32_t)((P.n + KH_Q_TILE - 1) / KH_Q_TILE);
+  uint32_t acc = 0;
   for (;;) {
     __syncthreads();                       // s_tile / s_wcnt / s_prefix of the previous tile have been read by every lane
     if (tid == 0) s_tile = atomicAdd(P.ticket, 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
-    if (tile >= ntiles) return;
-    const uint64_t base = (uint64_t)tile * KH_Q_TILE;
-    uint64_t key[KH_Q_ITEMS]; uint32_t val[KH_Q_ITEMS];
-    uint32_t valid = 0;
-#pragma unroll
-    for (int j = 0; j < KH_Q_ITEMS; ++j) {
-      const uint64_t i = base + (uint64_t)j * KH_Q_THREADS + tid;
-      key[j] = 0; val[j] = 0;
-      if (i < P.n) { key[j] = P.q[i]; valid |= 1u << j; }
+    if (tile >= ntiles) {
+      // per-query forms: the hit count was kept in registers over all the tiles of this workgroup -- one atomic per wave
+      // at exit (one per wave and tile were 39 K returning same-address atomics for 10^7 queries: 0.3 ms of serialisation)
+      if ((OUT == KH_FIND_PERQUERY || OUT == KH_FIND_COUNT) && P.n_found) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0 && acc) atomicAdd(P.n_found, (unsigned long long)acc);
+      }
+      return;
     }
-    const uint32_t hit = kh_probe_items<KIND, HASH>(P.T, key, valid, P.seed, val);
-    if (OUT == KH_FIND_PERQUERY || OUT == KH_FIND_COUNT) {
-      uint32_t c = 0;
+    const uint64_t base = (uint64_t)tile * KH_Q_TILE;
+    // the tile is probed in KH_Q_NB batches of KH_Q_ITEMS queries per lane; one look-back per tile ranks all of them.  The
+    // batch loop stays rolled (the registers of a batch -- 4 sectors of 4 slots per lane -- are reused by the next one); the
+    // values of the hits wait in LDS
+    uint32_t hit = 0;                                        // bit b * KH_Q_ITEMS + j
+#pragma unroll 1
+    for (int b = 0; b < KH_Q_NB; ++b) {
+      uint64_t key[KH_Q_ITEMS]; uint32_t v[KH_Q_ITEMS];
+      uint32_t valid = 0;
 #pragma unroll
       for (int j = 0; j < KH_Q_ITEMS; ++j) {
-        const uint64_t i = base + (uint64_t)j * KH_Q_THREADS + tid;
-        if ((valid >> j) & 1u) {
-          const bool f = (hit >> j) & 1u;
-          P.out_found[i] = f ? 1 : 0;
-          if (OUT == KH_FIND_PERQUERY && f && P.out_vals) P.out_vals[i] = val[j];
-          c += f ? 1u : 0u;
-        }
+        const uint64_t i = base + (uint64_t)(b * KH_Q_ITEMS + j) * KH_Q_THREADS + tid;
+        key[j] = 0; v[j] = 0;
+        if (i < P.n) { key[j] = P.q[i]; valid |= 1u << j; }
       }
-      if (P.n_found) {
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-        if (lane == 0 && c) atomicAdd(P.n_found, (unsigned long long)c);
-      }
-      continue;
-    }
-    // ---- ranks of the hits inside the tile (query order = j-major, then lane)
-    uint32_t before[KH_Q_ITEMS];
+      if (!__any(valid != 0)) continue;                      // (the last tile may end early)
+      const uint32_t h = kh_probe_items<KIND, HASH>(P.T, key, valid, P.seed, v);
+      hit |= h << (b * KH_Q_ITEMS);
+      if (OUT == KH_FIND_PERQUERY || OUT == KH_FIND_COUNT) {
 #pragma unroll
-    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+        for (int j = 0; j < KH_Q_ITEMS; ++j) {
+          const uint64_t i = base + (uint64_t)(b * KH_Q_ITEMS + j) * KH_Q_THREADS + tid;
+          if ((valid >> j) & 1u) {
+            const bool f = (h >> j) & 1u;
+            P.out_found[i] = f ? 1 : 0;
+            if (OUT == KH_FIND_PERQUERY && f && P.out_vals) P.out_vals[i] = v[j];
+            acc += f ? 1u : 0u;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KH_Q_ITEMS; ++j) s_val[(b * KH_Q_ITEMS + j) * KH_Q_THREADS + tid] = v[j];
+      }
+    }
+    if (OUT == KH_FIND_PERQUERY || OUT == KH_FIND_COUNT) continue;
+    // ---- ranks of the hits inside the tile (query order = (batch, item)-major, then lane)
+    uint32_t before[KH_Q_NB * KH_Q_ITEMS];
+#pragma unroll
+    for (int j = 0; j < KH_Q_NB * KH_Q_ITEMS; ++j) {
       const unsigned long long m = __ballot((hit >> j) & 1u);
       before[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (lane == 0) s_wcnt[j][wid] = (uint32_t)__popcll(m);
     }
     __syncthreads();
-    uint32_t off_j[KH_Q_ITEMS];
     uint32_t total = 0;
 #pragma unroll
-    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+    for (int j = 0; j < KH_Q_NB * KH_Q_ITEMS; ++j) {
       uint32_t mine = total;
 #pragma unroll
       for (uint32_t w2 = 0; w2 < KH_Q_THREADS / 64; ++w2) { const uint32_t c = s_wcnt[j][w2]; if (w2 < wid) mine += c; total += c; }
-      off_j[j] = mine;
+      before[j] += mine;
     }
     // ---- decoupled look-back (wave 0): exclusive prefix of this tile over the tiles before it
     if (wid == 0) {
@@ -263,16 +311,18 @@ __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
     }
     __syncthreads();
     const unsigned long long obase = s_prefix;
+    // the keys of the hits are read again (the batch's registers were reused; the tile's 32 KB of queries are L2-hot)
 #pragma unroll
-    for (int j = 0; j < KH_Q_ITEMS; ++j) {
+    for (int j = 0; j < KH_Q_NB * KH_Q_ITEMS; ++j) {
       if ((hit >> j) & 1u) {
-        const unsigned long long o = obase + off_j[j] + before[j];
+        const uint64_t key = P.q[base + (uint64_t)j * KH_Q_THREADS + tid];
+        const unsigned long long o = obase + before[j];
         if (OUT == KH_FIND_PAIRS) {
-          uint4 w; w.x = (uint32_t)key[j]; w.y = (uint32_t)(key[j] >> 32); w.z = val[j]; w.w = 0;
+          uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = s_val[j * KH_Q_THREADS + tid]; w.w = 0;
           *reinterpret_cast<uint4*>(P.out_pairs16 + o * 16) = w;
         } else {
-          P.out_keys[o] = key[j];
-          P.out_vals[o] = val[j];
+          P.out_keys[o] = key;
+          P.out_vals[o] = s_val[j * KH_Q_THREADS + tid];
         }
       }
     }
@@ -2137,123 +2187,179 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
 
 
 // ---------------------------------------------------------------------------------------------
-// Batches of middle size (10^2 .. 10^6 keys) into a LARGE Robin Hood table, in place.  The reference inserts such a batch
+// Batches of middle size (10^2 .. 10^5 keys) into a LARGE Robin Hood table, in place.  The reference inserts such a batch
 // in O(batch) (hashmap_robinhood.hpp:522-624); re-laying out the whole table for it costs O(table) (1.3-1.8 ms at 2^27
-// buckets: 10^4 keys would run slower than one CPU thread).  Here the table is cut into REGIONS of KH_L consecutive slots and
-// every region is owned by ONE lane, which applies the keys whose home bucket lies in its region one after the other with
+// buckets: 10^4 keys would run slower than one CPU thread).  Here the table is cut into REGIONS of KH_IP_L consecutive slots
+// and every region is owned by ONE lane, which applies the keys whose home bucket lies in its region one after the other with
 // the reference's single-key algorithms -- insert with displacement, backward-shift erase.  An operation that would read or
 // write a slot outside the owner's region (the displacement chain or the shift runs over the region's end) is not started:
 // the key goes to a deferred list.  No slot is touched by two lanes of one launch, so no inter-workgroup visibility is
-// needed inside a launch (per-XCD L2s are not coherent with each other).  The deferred keys (about 0.5 %: a chain crosses
-// a given boundary with probability ~ cluster length / 2048) are binned again with the regions shifted by half a region --
-// the old boundaries are interior now -- and what is deferred a second time (~0.003 %) is applied by a single lane.
+// needed inside a launch (per-XCD L2s are not coherent with each other).  The deferred keys (a few %: a chain crosses a
+// given boundary with probability ~ cluster length / 512) are binned again with the regions shifted by half a region --
+// the old boundaries are interior now -- and what is deferred a second time (chains longer than half a region, bins that
+// overflowed twice) is applied by a single lane.
 // The keys of an insert are DISTINCT and ABSENT from the table (k_dedup has folded duplicates and tested membership), so the
 // order in which they are applied does not matter: the Robin Hood layout is a function of the key set alone.
+// The host takes this path for at most ~1 key per region (n <= capacity / 512): every lane then runs a chain of a few dozen
+// dependent memory accesses; beyond that the whole-table re-layout, which streams, is faster.
 // ---------------------------------------------------------------------------------------------
-#define KH_IP_CAP 16             // keys binned per region and pass; more go to the deferred list
+#define KH_IP_LB 9
+#define KH_IP_L (1u << KH_IP_LB)  // slots per region
+#define KH_IP_CAP 8              // keys binned per region and pass; more go to the deferred list
 enum { KH_IP_INSERT = 0, KH_IP_ERASE = 1 };
 enum { KH_IP_DONE = 0, KH_IP_LEAVES_REGION = 1, KH_IP_TOO_FAR = 2, KH_IP_ABSENT = 3 };
 
+// The single-key algorithms below read the table in WINDOWS of KH_IP_W consecutive slots, all loads of a window in flight at
+// once: a chain of 15 dependent slot accesses (what the textbook loops are) costs 15 memory round trips, two windows cost two.
+
+#define KH_IP_W 16
 // Robin Hood insert of a key known to be absent (hashmap_robinhood.hpp:522-624 without the equality test).  BOUNDED: every
-// slot looked at must lie in [reg_start, reg_start + KH_L) (circular), otherwise nothing is written.
+// slot the decision depends on must lie in [reg_start, reg_start + KH_IP_L) (circular), otherwise nothing is written.
+// Pass 1 walks the displacement chain on the info bytes alone (distances only: where does the chain end, does a distance
+// pass 127, does it leave the region); pass 2 runs the same walk for real.
 template <bool BOUNDED>
 __device__ __forceinline__ int kh_rh_insert_absent(KhSlot* S, uint64_t mask, uint64_t home, uint64_t key, uint32_t val, uint64_t reg_start) {
-  uint64_t p = home;
-  uint32_t r = 0x80u;
-  // the slot the key takes: the first one whose resident is richer (closer to its home) or that is empty
-  for (;;) {
-    if (BOUNDED && ((p - reg_start) & mask) >= KH_L) return KH_IP_LEAVES_REGION;
-    const uint32_t inf = S[p].info & 0xFFu;
-    if (inf < r) break;
-    ++r; p = (p + 1) & mask;
-    if (r > 0xFFu) return KH_IP_TOO_FAR;
-  }
-  // dry run of the displacement chain: distances only
   {
-    uint64_t pp = p; uint32_t rr = r;
-    for (;;) {
-      if (BOUNDED && ((pp - reg_start) & mask) >= KH_L) return KH_IP_LEAVES_REGION;
-      const uint32_t cur = S[pp].info & 0xFFu;
-      if (cur == 0x00u) break;
-      if (cur < rr) rr = cur;                           // the resident is displaced and travels on with its own distance
-      ++rr; pp = (pp + 1) & mask;
-      if (rr > 0xFFu) return KH_IP_TOO_FAR;
+    uint64_t p0 = home;
+    uint32_t r = 0x80u;                                   // distance code of the element that is looking for a slot
+    bool end = false;
+    while (!end) {
+      uint32_t inf[KH_IP_W];
+#pragma unroll
+      for (int j = 0; j < KH_IP_W; ++j) inf[j] = S[(p0 + j) & mask].info & 0xFFu;
+#pragma unroll
+      for (int j = 0; j < KH_IP_W; ++j) {
+        if (!end) {
+          if (BOUNDED && ((p0 + j - reg_start) & mask) >= KH_IP_L) return KH_IP_LEAVES_REGION;
+          const uint32_t cur = inf[j];
+          if (cur == 0x00u) end = true;
+          else {
+            if (cur < r) r = cur;                         // the resident is displaced and travels on with its own distance
+            ++r;
+            if (r > 0xFFu) return KH_IP_TOO_FAR;
+          }
+        }
+      }
+      p0 += KH_IP_W;
     }
   }
-  uint64_t ck = key; uint32_t cv = val;
-  for (;;) {
-    const uint4 w = kh_slot_ld(S + p);
-    const uint32_t cur = w.w & 0xFFu;
-    if (cur == 0x00u) { kh_slot_st(S + p, ck, cv, r); break; }
-    if (cur < r) {
-      kh_slot_st(S + p, ck, cv, r);
-      ck = kh_slot_key(w); cv = w.z; r = cur;
+  uint64_t p0 = home;
+  uint64_t ck = key; uint32_t cv = val, r = 0x80u;
+  bool done = false;
+  while (!done) {
+    uint4 w[KH_IP_W];
+#pragma unroll
+    for (int j = 0; j < KH_IP_W; ++j) w[j] = kh_slot_ld(S + ((p0 + j) & mask));
+#pragma unroll
+    for (int j = 0; j < KH_IP_W; ++j) {
+      if (!done) {
+        const uint32_t cur = w[j].w & 0xFFu;
+        if (cur == 0x00u) { kh_slot_st(S + ((p0 + j) & mask), ck, cv, r); done = true; }
+        else {
+          if (cur < r) {
+            kh_slot_st(S + ((p0 + j) & mask), ck, cv, r);
+            ck = kh_slot_key(w[j]); cv = w[j].z; r = cur;
+          }
+          ++r;
+        }
+      }
     }
-    ++r; p = (p + 1) & mask;
+    p0 += KH_IP_W;
   }
   return KH_IP_DONE;
 }
 
-// Robin Hood erase by backward shift (hashmap_robinhood.hpp:1294-1356)
+// Robin Hood erase by backward shift (hashmap_robinhood.hpp:1294-1356).  Pass 1 finds the key and the end of the shift (the
+// first slot behind it that is empty or holds an element at its home); pass 2 moves the elements in between one slot down.
 template <bool BOUNDED>
 __device__ __forceinline__ int kh_rh_erase_one(KhSlot* S, uint64_t mask, uint64_t home, uint64_t key, uint64_t reg_start) {
-  uint64_t p = home;
-  uint32_t r = 0x80u;
-  for (;;) {
-    if (BOUNDED && ((p - reg_start) & mask) >= KH_L) return KH_IP_LEAVES_REGION;
-    const uint4 w = kh_slot_ld(S + p);
-    const uint32_t inf = w.w & 0xFFu;
-    if (inf < r) return KH_IP_ABSENT;
-    if (inf == r && kh_slot_key(w) == key) break;
-    ++r; p = (p + 1) & mask;
-    if (r > 0xFFu) return KH_IP_ABSENT;
-  }
-  if (BOUNDED) {     // the shift ends at the first slot that is empty or holds an element at its home: it must be ours to read
-    uint64_t q = (p + 1) & mask;
-    for (;;) {
-      if (((q - reg_start) & mask) >= KH_L) return KH_IP_LEAVES_REGION;
-      if ((S[q].info & 0xFFu) <= 0x80u) break;
-      q = (q + 1) & mask;
+  uint64_t at = 0, len = 0;                               // slot of the key; elements to move
+  {
+    uint64_t p0 = home;
+    uint32_t r = 0x80u;
+    int state = 0;                                        // 0 looking for the key, 1 looking for the end of the shift, 2 done
+    while (state != 2) {
+      uint4 w[KH_IP_W];
+#pragma unroll
+      for (int j = 0; j < KH_IP_W; ++j) w[j] = kh_slot_ld(S + ((p0 + j) & mask));
+#pragma unroll
+      for (int j = 0; j < KH_IP_W; ++j) {
+        if (state != 2) {
+          if (BOUNDED && ((p0 + j - reg_start) & mask) >= KH_IP_L) return KH_IP_LEAVES_REGION;
+          const uint32_t inf = w[j].w & 0xFFu;
+          if (state == 0) {
+            if (inf < r) return KH_IP_ABSENT;
+            if (inf == r && kh_slot_key(w[j]) == key) { at = (p0 + j) & mask; state = 1; }
+            else { ++r; if (r > 0xFFu) return KH_IP_ABSENT; }
+          } else {
+            if (inf <= 0x80u) state = 2; else ++len;
+          }
+        }
+      }
+      p0 += KH_IP_W;
     }
   }
-  uint64_t q = (p + 1) & mask;
-  for (;;) {
-    const uint4 w = kh_slot_ld(S + q);
-    if ((w.w & 0xFFu) <= 0x80u) break;
-    kh_slot_st(S + p, kh_slot_key(w), w.z, (w.w & 0xFFu) - 1u);
-    p = q; q = (q + 1) & mask;
+  uint64_t p0 = (at + 1) & mask;
+  for (uint64_t moved = 0; moved < len; moved += KH_IP_W) {
+    uint4 w[KH_IP_W];
+#pragma unroll
+    for (int j = 0; j < KH_IP_W; ++j) w[j] = kh_slot_ld(S + ((p0 + j) & mask));
+#pragma unroll
+    for (int j = 0; j < KH_IP_W; ++j)
+      if (moved + j < len) kh_slot_st(S + ((p0 + j - 1) & mask), kh_slot_key(w[j]), w[j].z, (w[j].w & 0xFFu) - 1u);
+    p0 += KH_IP_W;
   }
-  kh_slot_st(S + p, 0, 0, 0x00u);
+  kh_slot_st(S + ((at + len) & mask), 0, 0, 0x00u);
   return KH_IP_DONE;
 }
 
 struct KhInplaceParams {
   KhSlots T; uint64_t seed;
-  uint32_t ofs;                            // region r = slots [r * KH_L + ofs, (r + 1) * KH_L + ofs), circular
-  const ulonglong2* in_rec;                // input list as (key, value) records, or
-  const uint64_t* in_k; const uint32_t* in_v;   //   as key / value arrays (in_v null: values 0)
+  uint32_t ofs;                            // region r = slots [r * KH_IP_L + ofs, (r + 1) * KH_IP_L + ofs), circular
+  // the input list, one of: (key, value) records | key / value arrays (in_v null: values 0) | the per-partition lists
+  // k_dedup wrote (list q: part_cnt[q] entries of in_k / in_v from part_off[q] on; one workgroup per partition)
+  const ulonglong2* in_rec;
+  const uint64_t* in_k; const uint32_t* in_v;
+  const uint64_t* part_off; const uint32_t* part_cnt; uint32_t nparts;
   uint64_t n; const unsigned long long* n_dev;  // list length: n_dev != null overrides n (a count produced on the device)
   uint32_t* cnt;                           // [regions] zero at launch
   ulonglong2* bins;                        // [regions * KH_IP_CAP]
   ulonglong2* defer; unsigned long long* n_defer;      // keys not applied by this pass (n_defer zero at launch)
   unsigned long long* n_done;              // keys inserted / erased (accumulates over the passes)
+  unsigned long long* n_in;                // partition form: total list length (zero at launch)
   uint32_t* flags;
 };
 
 template <int HASH>
+__device__ __forceinline__ void kh_ip_bin_one(const KhInplaceParams& P, ulonglong2 rec, uint64_t mask) {
+  const uint64_t home = kh_hash64<HASH>(rec.x, P.seed) & mask;
+  const uint32_t r = (uint32_t)(((home - P.ofs) & mask) >> KH_IP_LB);
+  const uint32_t rank = atomicAdd(&P.cnt[r], 1u);
+  if (rank < KH_IP_CAP) P.bins[(uint64_t)r * KH_IP_CAP + rank] = rec;
+  else P.defer[atomicAdd(P.n_defer, 1ull)] = rec;
+}
+template <int HASH>
 __global__ void k_ip_bin(KhInplaceParams P) {
-  const uint64_t n = P.n_dev ? (uint64_t)*P.n_dev : P.n;
   const uint64_t mask = P.T.cap - 1;
+  if (P.part_off) {
+    for (uint32_t q = blockIdx.x; q < P.nparts; q += gridDim.x) {
+      const uint64_t b = P.part_off[q];
+      const uint32_t c = P.part_cnt[q];
+      if (threadIdx.x == 0 && c) atomicAdd(P.n_in, (unsigned long long)c);
+      for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
+        ulonglong2 rec; rec.x = P.in_k[b + i]; rec.y = P.in_v[b + i];
+        kh_ip_bin_one<HASH>(P, rec, mask);
+      }
+    }
+    return;
+  }
+  const uint64_t n = P.n_dev ? (uint64_t)*P.n_dev : P.n;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     ulonglong2 rec;
     if (P.in_rec) rec = P.in_rec[i];
     else { rec.x = P.in_k[i]; rec.y = P.in_v ? P.in_v[i] : 0u; }
-    const uint64_t home = kh_hash64<HASH>(rec.x, P.seed) & mask;
-    const uint32_t r = (uint32_t)(((home - P.ofs) & mask) >> KH_LB);
-    const uint32_t rank = atomicAdd(&P.cnt[r], 1u);
-    if (rank < KH_IP_CAP) P.bins[(uint64_t)r * KH_IP_CAP + rank] = rec;
-    else P.defer[atomicAdd(P.n_defer, 1ull)] = rec;
+    kh_ip_bin_one<HASH>(P, rec, mask);
   }
 }
 
@@ -2261,12 +2367,12 @@ __global__ void k_ip_bin(KhInplaceParams P) {
 template <int HASH, int OP>
 __global__ void k_ip_apply(KhInplaceParams P) {
   const uint64_t mask = P.T.cap - 1;
-  const uint32_t regions = (uint32_t)(P.T.cap >> KH_LB);
+  const uint32_t regions = (uint32_t)(P.T.cap >> KH_IP_LB);
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t done = 0;
   if (r < regions) {
     const uint32_t c = P.cnt[r] < KH_IP_CAP ? P.cnt[r] : KH_IP_CAP;
-    const uint64_t reg_start = ((uint64_t)r * KH_L + P.ofs) & mask;
+    const uint64_t reg_start = ((uint64_t)r * KH_IP_L + P.ofs) & mask;
     for (uint32_t j = 0; j < c; ++j) {
       const ulonglong2 rec = P.bins[(uint64_t)r * KH_IP_CAP + j];
       const uint64_t home = kh_hash64<HASH>(rec.x, P.seed) & mask;

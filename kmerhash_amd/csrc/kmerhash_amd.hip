@@ -868,48 +868,53 @@ kh_status small_batch(kh_table* t, const char* kb, uint32_t kstride, const char*
 }
 
 // ---- batches of middle size applied in place (Robin Hood; kh_kernels.h "Batches of middle size") --------------------------
-// Taken when no call of the batch can trigger a doubling (size + n <= max_load) and the batch is small against the table
-// (at most ~16 keys per region of 2048 slots): cost O(batch) instead of the O(table) re-layout.
+// Taken when no call of the batch can trigger a doubling (size + n <= max_load), the batch is small against the table (at
+// most ~1 key per region of 512 slots) and the load stays moderate (clusters much shorter than a region): cost O(batch)
+// instead of the O(table) re-layout.
 const bool g_disable_inplace = getenv("KH_DISABLE_INPLACE") != nullptr;      // test hook: force the re-layout
 inline bool inplace_ok(const kh_table* t, uint64_t n) {
-  return !g_disable_inplace && t->kind == KHK_RH && n > KH_SMALL_N && t->lsize > 0 && t->cur.cap >= 4 * (uint64_t)KH_L && n <= (t->cur.cap >> 7);
+  return !g_disable_inplace && t->kind == KHK_RH && n > KH_SMALL_N && t->lsize > 0 && t->cur.cap >= 16 * (uint64_t)KH_IP_L &&
+         n <= (t->cur.cap >> KH_IP_LB) && t->lsize + n <= threshold(t->cur.cap, 0.85f);
 }
-// the three passes over a list of (key, value) records / key array: regions, regions shifted by half, one lane
+inline size_t ws_inplace(const kh_table* t, uint64_t n) { return n * 32 + (t->cur.cap >> KH_IP_LB) * (size_t)(KH_IP_CAP * 16 + 8) + (size_t(1) << 20); }
+// result block of the in-place passes (device, zero at launch; copied to t->hpin in one piece)
+struct IpResult { unsigned long long defer1, defer2, done, n_in; uint32_t flags[KH_NFLAGS]; };
+// the three passes over the input list `src` describes (fields in_* / part_* / n of P0): regions, regions shifted by half, one lane
 template <int OP>
-kh_status inplace_passes(kh_table* t, const uint64_t* in_k, const uint32_t* in_v, uint64_t n_max, const unsigned long long* n_dev,
-                         unsigned long long** counters_out, uint32_t** flags_out) {
-  const uint32_t regions = (uint32_t)(t->cur.cap >> KH_LB);
-  uint32_t* cnt; ulonglong2 *bins, *defer1, *defer2; unsigned long long* c; uint32_t* flags;
-  TAKE(cnt, uint32_t, 2 * (size_t)regions);
+kh_status inplace_passes(kh_table* t, const KhInplaceParams& src, uint64_t n_max, IpResult** res_out) {
+  const uint32_t regions = (uint32_t)(t->cur.cap >> KH_IP_LB);
+  // one zero-initialised block: result + the two counter arrays
+  char* z; ulonglong2 *bins, *defer1, *defer2;
+  const size_t zbytes = sizeof(IpResult) + sizeof(uint32_t) * 2 * (size_t)regions;
+  TAKE(z, char, zbytes);
   TAKE(bins, ulonglong2, (size_t)regions * KH_IP_CAP);
   TAKE(defer1, ulonglong2, n_max); TAKE(defer2, ulonglong2, n_max);
-  TAKE(c, unsigned long long, 4);            // [0] deferred by pass 1, [1] deferred by pass 2, [2] keys done
-  TAKE(flags, uint32_t, KH_NFLAGS);
-  HIPCHK(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2 * (size_t)regions, t->stream));
-  HIPCHK(hipMemsetAsync(c, 0, 32, t->stream));
-  HIPCHK(hipMemsetAsync(flags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
-  KhInplaceParams P;
-  memset(&P, 0, sizeof(P));
-  P.T = t->cur; P.seed = t->seed; P.bins = bins; P.n_done = c + 2; P.flags = flags;
+  HIPCHK(hipMemsetAsync(z, 0, zbytes, t->stream));
+  IpResult* res = reinterpret_cast<IpResult*>(z);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(z + sizeof(IpResult));
+  KhInplaceParams P = src;
+  P.T = t->cur; P.seed = t->seed; P.bins = bins; P.n_done = &res->done; P.n_in = &res->n_in; P.flags = res->flags;
   const uint32_t apply_grid = (regions + 63) / 64;
   // pass 1: regions [r L, (r+1) L)
-  P.ofs = 0; P.in_k = in_k; P.in_v = in_v; P.n = n_max; P.n_dev = n_dev; P.cnt = cnt; P.defer = defer1; P.n_defer = c;
+  P.ofs = 0; P.cnt = cnt; P.defer = defer1; P.n_defer = &res->defer1;
   { Launch L(t, "k_ip_bin");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_bin<HASH>), dim3(grid_for(n_max, 256)), dim3(256), 0, t->stream, P)); }
+    const uint32_t grid = P.part_off ? std::min<uint32_t>(P.nparts, 4096u) : grid_for(n_max, 256);
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_bin<HASH>), dim3(grid), dim3(256), 0, t->stream, P)); }
   { Launch L(t, "k_ip_apply");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_apply<HASH, OP>), dim3(apply_grid), dim3(64), 0, t->stream, P)); }
   // pass 2: what crossed a boundary, regions shifted by half a region
-  P.ofs = KH_L / 2; P.in_k = nullptr; P.in_v = nullptr; P.in_rec = defer1; P.n = 0; P.n_dev = c; P.cnt = cnt + regions; P.defer = defer2; P.n_defer = c + 1;
-  { Launch L(t, "k_ip_bin");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_bin<HASH>), dim3(grid_for(std::max<uint64_t>(n_max / 16, 256), 256)), dim3(256), 0, t->stream, P)); }
-  { Launch L(t, "k_ip_apply");
+  P.ofs = KH_IP_L / 2; P.in_k = nullptr; P.in_v = nullptr; P.part_off = nullptr; P.in_rec = defer1; P.n = 0; P.n_dev = &res->defer1;
+  P.cnt = cnt + regions; P.defer = defer2; P.n_defer = &res->defer2;
+  { Launch L(t, "k_ip_bin2");
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_bin<HASH>), dim3(grid_for(std::max<uint64_t>(n_max / 8, 256), 256)), dim3(256), 0, t->stream, P)); }
+  { Launch L(t, "k_ip_apply2");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_apply<HASH, OP>), dim3(apply_grid), dim3(64), 0, t->stream, P)); }
   // pass 3: the rest, one lane
-  P.in_rec = defer2; P.n_dev = c + 1;
+  P.in_rec = defer2; P.n_dev = &res->defer2;
   { Launch L(t, "k_ip_serial");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_serial<HASH, OP>), dim3(1), dim3(64), 0, t->stream, P)); }
   HIPCHK(hipGetLastError());
-  *counters_out = c; *flags_out = flags;
+  *res_out = res;
   return KH_OK;
 }
 
@@ -917,7 +922,7 @@ kh_status insert_inplace(kh_table* t, const char* kb, uint32_t kstride, const ch
   *n_new_out = 0;
   // equal keys must meet: partition by a few hash bits into pieces of ~1024 records (one pass), fold duplicates in LDS and
   // test membership against the table (k_dedup: updates / sums of EXISTING keys happen there); what comes out are the
-  // batch's distinct NEW keys
+  // batch's distinct NEW keys, one list per partition, which the binning kernel reads where they lie
   uint32_t PB = 0;
   while (PB < 11 && (n >> PB) > 1024) ++PB;
   ulonglong2 *tmp, *fin;
@@ -928,25 +933,26 @@ kh_status insert_inplace(kh_table* t, const char* kb, uint32_t kstride, const ch
   KhSrcSet S;
   memset(&S, 0, sizeof(S));
   S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off;
-  uint32_t* cnt_new; uint64_t* noff; unsigned long long* scal; uint32_t* dflags; uint64_t* gk; uint32_t* gv;
-  TAKE(cnt_new, uint32_t, R.nparts); TAKE(noff, uint64_t, R.nparts + 1); TAKE(scal, unsigned long long, 4); TAKE(dflags, uint32_t, KH_NFLAGS);
-  TAKE(gk, uint64_t, n); TAKE(gv, uint32_t, n);
-  HIPCHK(hipMemsetAsync(scal, 0, 32, t->stream));
-  HIPCHK(hipMemsetAsync(dflags, 0, sizeof(uint32_t) * KH_NFLAGS, t->stream));
+  uint32_t* cnt_new;
+  TAKE(cnt_new, uint32_t, R.nparts);
+  KhInplaceParams src;
+  memset(&src, 0, sizeof(src));
+  src.in_k = reinterpret_cast<uint64_t*>(R.spare); src.in_v = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(R.spare) + n * 8);
+  src.part_off = R.part_off; src.part_cnt = cnt_new; src.nparts = R.nparts;
   KhDedupParams D;
   memset(&D, 0, sizeof(D));
   D.src = S;
-  D.nk = reinterpret_cast<uint64_t*>(R.spare); D.nv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(R.spare) + n * 8);
-  D.cnt_new = cnt_new; D.max_idx_plus1 = scal; D.count_cap = 0; D.PB = PB;
-  D.T = t->cur; D.seed = t->seed; D.table_empty = 0; D.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST; D.flags = dflags;
+  D.nk = const_cast<uint64_t*>(src.in_k); D.nv = const_cast<uint32_t*>(src.in_v);
+  D.cnt_new = cnt_new; D.count_cap = 0; D.PB = PB;
+  D.T = t->cur; D.seed = t->seed; D.table_empty = 0; D.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST;
+  char* zpre;                   // k_dedup's scalar and flag words
+  TAKE(zpre, char, 64);
+  HIPCHK(hipMemsetAsync(zpre, 0, 64, t->stream));
+  D.max_idx_plus1 = reinterpret_cast<unsigned long long*>(zpre); D.flags = reinterpret_cast<uint32_t*>(zpre + 32);
   { Launch L(t, "k_dedup");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
-  { Launch L(t, "k_scan");
-    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, cnt_new, (uint64_t)R.nparts, noff); }
-  { Launch L(t, "k_gather_new");
-    hipLaunchKernelGGL(k_gather_new, dim3(R.nparts), dim3(256), 0, t->stream, S.merged_off, noff, D.nk, D.nv, gk, gv); }
-  unsigned long long* c; uint32_t* flags;
-  st = inplace_passes<KH_IP_INSERT>(t, gk, gv, n, reinterpret_cast<const unsigned long long*>(noff + R.nparts), &c, &flags);
+  IpResult* res = nullptr;
+  st = inplace_passes<KH_IP_INSERT>(t, src, n, &res);
   if (st != KH_OK) return st;
   if (mode == INS_UPDATE) {   // update(k,v): every key of the batch is in the table now; it takes the value of its LAST occurrence
     D.mode = KH_DEDUP_LAST;
@@ -954,16 +960,15 @@ kh_status insert_inplace(kh_table* t, const char* kb, uint32_t kstride, const ch
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D));
     HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipMemcpyAsync(t->hpin, noff + R.nparts, 8, hipMemcpyDeviceToHost, t->stream));
-  HIPCHK(hipMemcpyAsync(t->hpin + 1, c, 24, hipMemcpyDeviceToHost, t->stream));
-  HIPCHK(hipMemcpyAsync(t->hpin + 4, flags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
-  HIPCHK(hipMemcpyAsync(t->hpin + 8, dflags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipMemcpyAsync(t->hpin, res, sizeof(IpResult), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipMemcpyAsync(t->hpin + 32, zpre, 64, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
-  const uint64_t dnew = t->hpin[0], placed = t->hpin[3];
+  const IpResult* h = reinterpret_cast<const IpResult*>(t->hpin);
+  const uint64_t dnew = h->n_in, placed = h->done;
   t->lsize += placed;
   *n_new_out = placed;
-  if (reinterpret_cast<const uint32_t*>(t->hpin + 8)[KH_FLAG_INTERNAL]) return fail(t, KH_ERR_HIP, "internal: de-duplication set overflow");
-  if (placed != dnew || reinterpret_cast<const uint32_t*>(t->hpin + 4)[KH_FLAG_PROBE_OVERFLOW])
+  if (reinterpret_cast<const uint32_t*>(t->hpin + 32 + 4)[KH_FLAG_INTERNAL]) return fail(t, KH_ERR_HIP, "internal: de-duplication set overflow");
+  if (placed != dnew || h->flags[KH_FLAG_PROBE_OVERFLOW])
     return fail(t, KH_ERR_PROBE_OVERFLOW, "Robin Hood probe distance would exceed 127 (7-bit info field, hashmap_robinhood.hpp:142-144,556); "
                                           "the keys of the batch that fit were applied in place");
   return KH_OK;
@@ -977,7 +982,7 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
   HIPCHK(hipSetDevice(t->device));
   { const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n ? n : 1, n, n ? n - 1 : 0);
     const bool ip = inplace_ok(t, n) && t->lsize + n <= t->max_load;      // in place: no re-layout workspace, bins instead
-    kh_status ps = ip ? arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 80 + (t->cur.cap >> KH_LB) * (size_t)(KH_IP_CAP * 16 + 8) + (size_t(2) << 20))
+    kh_status ps = ip ? arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_inplace(t, n))
                       : arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
     if (ps != KH_OK) return ps; }
   const char* kb = static_cast<const char*>(keys);
@@ -1071,7 +1076,8 @@ kh_status launch_find(kh_table* t, int out_mode, const uint64_t* q, uint64_t n, 
   memset(&F, 0, sizeof(F));
   F.T = t->cur; F.q = q; F.n = n; F.seed = t->seed;
   F.out_vals = dvals; F.out_found = dfound; F.out_keys = dkeys; F.out_pairs16 = dpairs;
-  F.n_found = ctl; F.ticket = reinterpret_cast<uint32_t*>(ctl + 1); F.tile_state = ctl + 2;
+  F.n_found = (out_mode == KH_FIND_COUNT && !hits_dev) ? nullptr : ctl;      // count(Iter,Iter) returns no total
+  F.ticket = reinterpret_cast<uint32_t*>(ctl + 1); F.tile_state = ctl + 2;
   int ncu = 256;
   hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, t->device);
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, (uint64_t)ncu * 8));
@@ -1151,7 +1157,7 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
   if (n == 0) return KH_OK;
   if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
-  { kh_status ps = inplace_ok(t, n) ? arena_prepare(t, n * 40 + (t->cur.cap >> KH_LB) * (size_t)(KH_IP_CAP * 16 + 8) + (size_t(2) << 20))
+  { kh_status ps = inplace_ok(t, n) ? arena_prepare(t, n * 8 + ws_inplace(t, n))
                                     : arena_prepare(t, n * 8 + ws_rebuild(t->cur.cap) + (size_t(1) << 20));
     if (ps != KH_OK) return ps; }
   const uint64_t* q;
@@ -1166,10 +1172,13 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
     return KH_OK;
   }
   if (inplace_ok(t, n)) {       // backward-shift deletes in place, one lane per region of the table
-    unsigned long long* c; uint32_t* flags;
-    st = inplace_passes<KH_IP_ERASE>(t, q, nullptr, n, nullptr, &c, &flags);
+    KhInplaceParams src;
+    memset(&src, 0, sizeof(src));
+    src.in_k = q; src.n = n;
+    IpResult* res = nullptr;
+    st = inplace_passes<KH_IP_ERASE>(t, src, n, &res);
     if (st != KH_OK) return st;
-    HIPCHK(hipMemcpyAsync(t->hpin, c + 2, 8, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipMemcpyAsync(t->hpin, &res->done, 8, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     t->lsize -= t->hpin[0];
     *n_erased = t->hpin[0];

@@ -23,3 +23,10 @@ for m in (100, 1000, 10_000, 100_000, 1_000_000):
         if rep: ti.append(a); te.append(b)
     print("batch %8d: insert %8.3f ms (%7.2f M keys/s)   erase %8.3f ms (%7.2f M keys/s)" % (m, np.median(ti), m / np.median(ti) / 1e3, np.median(te), m / np.median(te) / 1e3), flush=True)
 print(t.profile() if False else "capacity %d size %d" % (t.capacity(), t.size()))
+for m in (100, 10_000, 100_000):
+    t.profile_reset(); t.profile_enable(True)
+    k = torch.from_numpy(fresh[3_000_000:3_000_000 + m].view(np.int64)).cuda(); v = torch.arange(m, dtype=torch.int32, device="cuda")
+    t.insert(k, v); pi = t.profile(); t.profile_reset()
+    t.erase(k); pe = t.profile(); t.profile_enable(False)
+    print("batch %d insert kernels (launches, ms):" % m, {a: (b[0], round(b[1], 4)) for a, b in pi.items()})
+    print("batch %d erase kernels:" % m, {a: (b[0], round(b[1], 4)) for a, b in pe.items()})

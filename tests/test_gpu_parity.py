@@ -830,8 +830,8 @@ def test_mid_size_batches_are_applied_in_place(oracle, hname, hid):
     """10^2..10^6 keys into a large Robin Hood table cost O(batch): the table is cut into regions owned by one
     lane each, keys whose displacement chain / backward shift would leave the region are deferred to a pass with shifted
     regions, the rest to a single lane (hashmap_robinhood.hpp:522-624,1294-1356).  Bit-exact info array after every step."""
-    cap = 1 << 20                                              # 512 regions; in place for 17..8192 keys
-    base = W.distinct_u64(600_000, seed=77)
+    cap = 1 << 22                                              # 8192 regions of 512 slots; in place for 17..8192 keys
+    base = W.distinct_u64(2_400_000, seed=77)
     bv = np.arange(len(base), dtype=np.uint32)
     g = kh.hashmap_robinhood_doubling(cap, 0.35, 0.8, hash=hname, seed=43)
     o = oracle.OracleTable(0, cap, 0.35, 0.8, hid, 43)
@@ -850,7 +850,7 @@ def test_mid_size_batches_are_applied_in_place(oracle, hname, hid):
         check_state(g, o, 0)
     assert g.capacity() == cap
     prof = g.profile()
-    assert prof["k_ip_apply"][0] == 10 and "k_rebuild_fused" not in prof and "k_insert_fused" not in prof, prof
+    assert prof["k_ip_apply"][0] == 5 and "k_rebuild_fused" not in prof and "k_insert_fused" not in prof, prof
     # update: existing keys take the last value, new ones are inserted
     k = np.concatenate([fresh[pos:pos + 3000], base[:2000], fresh[pos:pos + 500]]); pos += 3000
     v = np.arange(len(k), dtype=np.uint32) + np.uint32(9)
@@ -863,7 +863,7 @@ def test_mid_size_batches_are_applied_in_place(oracle, hname, hid):
         e = np.concatenate([base[rng.integers(0, len(base), n - n // 5)], W.distinct_u64(n // 5, seed=1000 + n)])
         assert g.erase(dev(e)) == o.erase(e)
         check_state(g, o, 0)
-    assert g.profile()["k_ip_apply"][0] == 18
+    assert g.profile()["k_ip_apply"][0] == 9
     check_queries(g, o, np.concatenate([base[:3000], fresh[:3000], W.distinct_u64(1000, seed=4)]))
     # counting insert (std::plus) in place
     k = np.concatenate([fresh[pos:pos + 2000], fresh[pos:pos + 2000], base[:1000]])
@@ -879,10 +879,9 @@ def test_mid_size_batches_are_applied_in_place(oracle, hname, hid):
 
 
 def test_mid_size_in_place_region_boundaries(oracle):
-    """identity hash, crafted homes: chains that cross a region boundary (pass 2), chains that cross a regular AND a shifted
-    boundary (a run of 1100 occupied slots over 1024 and 2048: pass 3, the single lane), and more keys in one region than a
-    bin holds"""
-    cap = 1 << 16                                              # 32 regions of 2048 slots; in place for 17..512 keys
+    """identity hash, crafted homes: chains that cross a region boundary (pass 2), chains that cross regular AND shifted
+    boundaries (a run of 1100 occupied slots: pass 3, the single lane), and more keys in one region than a bin holds"""
+    cap = 1 << 16                                              # 128 regions of 512 slots; in place for 17..128 keys
     run = np.arange(1000, 2100, dtype=np.uint64)               # every slot of [1000, 2100) holds an element at its home
     sparse = np.arange(4096, 60_000, 7, dtype=np.uint64)
     keys = np.concatenate([run, sparse])
