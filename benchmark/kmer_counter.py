@@ -1,53 +1,189 @@
 #!/usr/bin/env python3
-"""BenchmarkKmerCounter shape on one GPU (reference benchmark/BenchmarkKmerCounter.cpp:1476-1787: read FASTQ in batches ->
-canonical 31-mers -> counting insert -> write (k-mer,count) tuples), on a synthetic FASTQ (random genome, 150-bp reads).
-Informational driver for the SURVEY 8f-2 row; the contract benchmark is ../bench.py."""
+"""BASELINE configs[4] shape: the distributed k-mer counter with its query cycle, on synthetic FASTQ.
+
+Reference: benchmark/BenchmarkKmerCounter.cpp:1476-1787 (read the input in file batches -> canonical 31-mers -> counting
+insert into dsc::counting_batched_robinhood_map, farmhash storage hash, the table doubling under load) followed by the
+query phase of benchmark/BenchmarkKmerIndex.cpp:787-843 (count, find, erase over a sample of the input).
+
+  python benchmark/kmer_counter.py [--gpus N] [--reads R] [--batches B] [--cycle] ...
+
+Every rank owns R reads of ONE synthetic genome (150-bp error-free reads on both strands: the count of every k-mer is then
+predictable from the read positions alone, which is what --verify checks at any scale), parses its FASTQ text on its GPU
+(kh_kmers_from_fastq: record structure, 2-bit packing and canonicalisation), and feeds the k-mers to the sharded counting
+table (kmerhash_amd.dist.ShardedTable.insert_counts: hash partition, RCCL exchange, local std::plus insert; one rank: no
+exchange).  Launch model as bench.py: without WORLD_SIZE this process starts the N ranks itself and never touches a GPU.
+Prints ONE JSON line (rank 0).  Informational driver for SURVEY 8f-2 / configs[4]; the contract benchmark is ../bench.py."""
 import argparse
+import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
-def main():
+def parse(argv):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--reads", type=int, default=2_000_000)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=2_000_000, help="reads per rank")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome", type=int, default=20_000_000)
-    ap.add_argument("--batches", type=int, default=4, help="file batches (the reference reads the input in memory-sized pieces)")
+    ap.add_argument("--batches", type=int, default=4, help="file batches per rank (the reference reads the input in memory-sized pieces)")
     ap.add_argument("-k", type=int, default=31)
-    ap.add_argument("--out", default="")
-    ap.add_argument("--raw-fastq", action="store_true", help="feed raw FASTQ text: the record structure is resolved on the GPU (kh_kmers_from_fastq)")
-    a = ap.parse_args()
+    ap.add_argument("--hash", default="farm", choices=["farm", "murmur3avx64", "murmur"])
+    ap.add_argument("--chunks", type=int, default=0, help="pieces of the pipelined exchange per batch (0 = 4 when N > 1)")
+    ap.add_argument("--cycle", action="store_true", help="run the count / find / erase / count query cycle after the inserts")
+    ap.add_argument("--sample-ratio", type=int, default=100, help="queries = every s-th k-mer of the rank's input (BenchmarkKmerIndex -q sampling)")
+    ap.add_argument("--hll-reserve", action="store_true", help="pre-size the table from a HyperLogLog estimate per batch instead of doubling under load")
+    ap.add_argument("--verify", action="store_true", help="check size, total count and a sample of 10^5 k-mer counts against the prediction from the read positions")
+    ap.add_argument("--out", default="", help="write this rank's (k-mer, count) tuples (BenchmarkKmerCounter.cpp:1022-1211)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(args, argv):
+    import torch
+    if torch.cuda.device_count() < args.gpus:
+        print("[kmer_counter] --gpus %d requested, %d visible" % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def run_rank(args):
+    world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("[kmer_counter] WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+        return 2
     import torch
     from kmerhash_amd import kmers as KM
+    from kmerhash_amd import dist as khd
+    from kmerhash_amd.hll import hyperloglog64
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    chunks = args.chunks if args.chunks > 0 else (4 if world > 1 else 1)
+
+    # ---- input: this rank's reads of the common genome (host generation is not timed)
     t0 = time.perf_counter()
-    seq = (KM.synthetic_fastq_fixed if a.raw_fastq else KM.synthetic_read_sequences)(a.reads, a.read_len, a.genome, seed=7)
+    seq, genome, starts, rev = KM.synthetic_reads(args.reads, args.read_len, args.genome, genome_seed=7, read_seed=100 + rank)   # one genome, own reads
+    fq = KM.fastq_from_sequence_lines(seq, args.reads, args.read_len)
     t_gen = time.perf_counter() - t0
-    dseq = torch.from_numpy(seq).cuda()
-    kc = KM.KmerCounter(a.k, canonical=True, hash="farm")
-    # batches cut at read boundaries
-    nl = np.flatnonzero(seq == 10)
-    if a.raw_fastq:
-        nl = nl[3::4]                            # record ends
-    cuts = [0] + [int(nl[len(nl) * i // a.batches - 1]) + 1 for i in range(1, a.batches)] + [len(seq)]
-    torch.cuda.synchronize()
+    dfq = torch.from_numpy(fq).to(dev)
+    rec = len(fq) // args.reads
+    cuts = [rec * (args.reads * i // args.batches) for i in range(args.batches + 1)]
+
+    be = khd.GpuBackend(local, "rh", 128, 0.35, 0.8, args.hash, 43)
+    st = khd.ShardedTable(be, timing=True)
+    hll = hyperloglog64(12, 0, args.hash, 43, local) if args.hll_reserve else None
+    kc = KM.ShardedKmerCounter(st, args.k, True, chunks=chunks, reserve_from_estimate=args.hll_reserve, hll=hll)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    caps = []
+    sync()
     t0 = time.perf_counter()
-    total = 0
-    for i in range(a.batches):
-        total += (kc.add_fastq if a.raw_fastq else kc.add_sequences)(dseq[cuts[i]:cuts[i + 1]])
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    print("%s bytes %d  k-mers %d  distinct %d  capacity %d" % ("FASTQ" if a.raw_fastq else "sequence", len(seq), total, kc.table.size(), kc.table.capacity()))
-    print("generate+parse (host) %.2f s ; k-mer generation + counting (device, %d batches) %.4f s = %.3f G k-mers/s"
-          % (t_gen, a.batches, dt, total / dt / 1e9))
-    if a.out:
-        print("wrote %d tuples to %s" % (kc.write(a.out), a.out))
-    kc.close()
+    for i in range(args.batches):
+        kc.add_fastq(dfq[cuts[i]:cuts[i + 1]])
+        caps.append(be.table.capacity())
+    sync()
+    t_ins = time.perf_counter() - t0
+    total_local = kc.total_kmers
+    size_after = kc.size()
+    res = {"kmers_local": total_local, "capacity_per_batch_rank0": caps, "distinct_global": size_after,
+           "insert_s": t_ins, "phases_ms_rank0": {k: round(v, 3) for k, v in st.timings().items()}}
+
+    ok = True
+    if args.verify:
+        # counts predicted from the read positions of ALL ranks (cov[p] = reads covering the k-mer at genome position p)
+        cov = np.zeros(args.genome, dtype=np.int64)
+        for r in range(world):
+            s_r = starts if r == rank else KM.read_positions(args.reads, args.read_len, args.genome, 100 + r)[0]
+            cov += KM.expected_kmer_coverage(args.genome, s_r, args.read_len, args.k)
+        exp_total = int(cov.sum())
+        exp_distinct = int((cov > 0).sum())                        # exact when the genome's k-mers are pairwise distinct (k = 31: they are)
+        rng = np.random.default_rng(99 + rank)
+        pos = rng.integers(0, args.genome - args.k, 100_000)
+        qk = KM.canonical_kmers_at(genome, pos, args.k)
+        pk, vals, found = st.find(torch.from_numpy(qk.view(np.int64)).to(dev))
+        got = dict(zip(pk.cpu().numpy().view(np.uint64).tolist(), ((vals.cpu().numpy().view(np.uint32).astype(np.int64)) * found.cpu().numpy()).tolist()))
+        exp = {}
+        for kk, c in zip(qk.tolist(), cov[pos].tolist()):
+            exp[kk] = c                                            # (a k-mer sampled twice has the same position-independent count)
+        bad = sum(1 for kk, c in exp.items() if got.get(kk, -1) != (c & 0xFFFFFFFF))
+        tot = torch.tensor([total_local], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(tot)
+        ok = bad == 0 and int(tot.item()) == exp_total and size_after == exp_distinct
+        res["verify"] = {"ok": bool(ok), "sample_mismatches": bad, "total_kmers": int(tot.item()), "expected_total": exp_total,
+                         "expected_distinct": exp_distinct}
+
+    if args.cycle:
+        # queries: every s-th k-mer of this rank's first batch (BenchmarkKmerIndex samples the input file the same way)
+        km = KM.kmers_from_fastq(dfq[cuts[0]:cuts[1]], args.k, True, local)
+        qs = km[:: args.sample_ratio].contiguous()
+        sync()
+        t0 = time.perf_counter()
+        cyc = kc.cycle(qs)
+        sync()
+        t_cyc = time.perf_counter() - t0
+        nq = int(qs.numel())
+        ok = ok and cyc["count_hits"] == nq and cyc["find_hits"] == nq and cyc["count_hits_after"] == 0
+        res["cycle"] = dict(cyc, queries_local=nq, seconds=t_cyc, size_after=kc.size(), ok=bool(cyc["count_hits"] == nq and cyc["count_hits_after"] == 0))
+    if args.out:
+        k_, v_ = be.table.to_vector()
+        recs = np.zeros(len(k_), dtype=np.dtype([("kmer", "<u8"), ("count", "<u2")]))
+        recs["kmer"] = k_; recs["count"] = v_.astype(np.uint16)
+        recs.tofile(args.out + (".%d" % rank if world > 1 else ""))
+    if rank == 0:
+        res.update({"n_gpus": world, "reads_per_rank": args.reads, "batches": args.batches, "k": args.k, "hash": args.hash,
+                    "exchange_pieces": chunks, "fastq_bytes_per_rank": int(len(fq)), "host_generation_s": round(t_gen, 2),
+                    "kmers_per_s": total_local * world / t_ins, "ok": bool(ok)})
+        print(json.dumps(res), flush=True)
+    be.table.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if "WORLD_SIZE" in os.environ:
+        return run_rank(args)
+    if args.gpus == 1:
+        os.environ.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+        return run_rank(args)
+    return launch(args, argv)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -209,6 +209,9 @@ class ShardedTable:
         return [next(it) if s is not None else None for s in sends]
 
     def _route(self, keys, vals=None):
+        if self._single():             # one rank owns every key: nothing to permute or exchange
+            n = int(keys.numel())
+            return keys, keys, vals, [n], [n]
         with self._span("permute"):
             ok, ov, sc = self.b.shard(keys, vals, self.p)
         rc = self._exchange_counts(sc)

@@ -163,3 +163,120 @@ def synthetic_fastq_fixed(n_reads, read_len=150, genome_len=1_000_000, seed=7, n
     out[:, o + 2 + read_len] = 10
     return out.reshape(-1)
 
+
+
+class ShardedKmerCounter:
+    """BASELINE configs[4]: the distributed k-mer counter.  BenchmarkKmerCounter.cpp:1476-1787 reads the input in file batches,
+    turns every batch into canonical k-mers, and inserts them into dsc::counting_batched_robinhood_map (Reducer = std::plus,
+    distributed_batched_robinhood_map.hpp:2542-2950): every rank parses ITS share of the reads, the k-mers are sharded by
+    murmur3(k-mer, seed 9876543) over the ranks (kmerhash_amd.dist.ShardedTable: RCCL exchange, pipelined) and counted in the
+    owner's local table, which starts at capacity 128 and doubles under load (or is pre-sized from a HyperLogLog estimate,
+    robinhood_offset_hashmap_ptr.hpp:2512-2535, with reserve_from_estimate=True).  cycle() is the query phase of
+    BenchmarkKmerIndex.cpp:787-843: count, find, erase over a sample of the input, then count again.
+
+    `sharded` is a kmerhash_amd.dist.ShardedTable (any backend); `kmer_fn(text) -> packed canonical k-mers` is the k-mer
+    generator (default: kh_kmers_from_fastq on this rank's GPU)."""
+
+    def __init__(self, sharded, k=31, canonical=True, kmer_fn=None, chunks=1, reserve_from_estimate=False, hll=None):
+        self.st, self.k, self.canonical, self.chunks = sharded, k, canonical, chunks
+        dev = getattr(sharded.b, "device", 0)
+        self.kmer_fn = kmer_fn if kmer_fn is not None else (lambda text: kmers_from_fastq(text, k, canonical, dev))
+        self.reserve_from_estimate = reserve_from_estimate
+        self.hll = hll
+        self.total_kmers = 0
+
+    def add_fastq(self, text):
+        """one file batch of this rank: raw FASTQ text (whole records) -> k-mers -> sharded counting insert.  Collective: every
+        rank calls it once per batch (an empty batch where a rank has run out of reads)."""
+        km = self.kmer_fn(text)
+        if self.reserve_from_estimate and self.hll is not None and len(km):
+            # the reference sizes its counting table from a HyperLogLog estimate of the distinct k-mers seen so far (+ the
+            # estimator's standard error 1.04 / sqrt(m)) before it inserts; the estimate is per rank, of what the rank HOLDS,
+            # so it is taken over the received keys' owner-side image: every rank sees ~1/p of the global distinct set
+            self.hll.update(km)
+            est = self.hll.estimate() / max(self.st.p, 1)
+            self.st.local.reserve(int(est * (1.0 + self.hll.est_error_rate)))
+        self.st.insert_counts(km, chunks=self.chunks)
+        self.total_kmers += len(km)
+        return len(km)
+
+    def cycle(self, queries):
+        """count -> find -> erase -> count over `queries` (this rank's sample; collective).  Returns per-rank numbers:
+        hits of the first count, sum of the counts find returned, keys erased on this rank's local table, hits afterwards."""
+        _, c1 = self.st.count(queries)
+        _, vals, found = self.st.find(queries)
+        erased = self.st.erase(queries)
+        _, c2 = self.st.count(queries)
+        occ = (vals.to(torch.int64) & 0xFFFFFFFF) * found.to(torch.int64)
+        return {"count_hits": int(c1.sum()), "find_hits": int(found.sum()), "find_occurrences": int(occ.sum()),
+                "erased_local": int(erased), "count_hits_after": int(c2.sum())}
+
+    def size(self):
+        return self.st.size()
+
+
+def read_positions(n_reads, read_len, genome_len, read_seed):
+    """(starts, strand flags) of the reads synthetic_reads draws for `read_seed`"""
+    rng = np.random.default_rng(read_seed)
+    starts = rng.integers(0, genome_len - read_len, n_reads, dtype=np.int32)
+    rev = rng.integers(0, 2, n_reads, dtype=np.uint8).astype(bool)
+    return starts, rev
+
+
+def synthetic_reads(n_reads, read_len=150, genome_len=1_000_000, genome_seed=7, read_seed=8):
+    """error-free reads of a random genome on both strands, with what is needed to PREDICT every k-mer's count: returns
+    (sequence lines as synthetic_read_sequences lays them out, genome codes, read starts, strand flags).  Ranks of a
+    distributed run share genome_seed and differ in read_seed."""
+    genome = np.random.default_rng(genome_seed).integers(0, 4, genome_len, dtype=np.uint8)
+    starts, rev = read_positions(n_reads, read_len, genome_len, read_seed)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = np.empty((n_reads, read_len + 1), dtype=np.uint8)
+    ar = np.arange(read_len, dtype=np.int32)[None, :]
+    for c0 in range(0, n_reads, 100_000):
+        c1 = min(n_reads, c0 + 100_000)
+        r = genome[starts[c0:c1, None] + ar]
+        rr = rev[c0:c1]
+        r[rr] = (3 - r[rr])[:, ::-1]
+        out[c0:c1, :read_len] = lut[r]
+    out[:, read_len] = 10
+    return out.reshape(-1), genome, starts, rev
+
+
+def fastq_from_sequence_lines(seq_lines, n_reads, read_len):
+    """fixed-width FASTQ text around the given sequence lines (the layout of synthetic_fastq_fixed)"""
+    seq = seq_lines.reshape(n_reads, read_len + 1)
+    w = 1 + 11 + 1 + (read_len + 1) + 2 + (read_len + 1)
+    out = np.empty((n_reads, w), dtype=np.uint8)
+    out[:, 0] = ord("@")
+    ids = np.arange(n_reads, dtype=np.int64)
+    for d in range(11):
+        out[:, 11 - d] = ord("0") + (ids % 10)
+        ids //= 10
+    out[:, 12] = 10
+    out[:, 13: 13 + read_len + 1] = seq
+    o = 13 + read_len + 1
+    out[:, o] = ord("+"); out[:, o + 1] = 10
+    out[:, o + 2: o + 2 + read_len] = ord("I")
+    out[:, o + 2 + read_len] = 10
+    return out.reshape(-1)
+
+
+def expected_kmer_coverage(genome_len, starts, read_len, k):
+    """cov[p] = number of reads that contain the k-mer starting at genome position p (either strand: the canonical k-mer of a
+    window is the same on both): the count the table must hold for that k-mer when the genome's k-mers are all distinct"""
+    d = np.zeros(genome_len + 1, dtype=np.int64)
+    np.add.at(d, starts, 1)
+    np.add.at(d, starts + (read_len - k + 1), -1)
+    return np.cumsum(d)[:genome_len]
+
+
+def canonical_kmers_at(genome, positions, k):
+    """packed canonical k-mers of the genome windows starting at `positions` (numpy; A0 C1 G2 T3, first base most significant)"""
+    pos = np.asarray(positions, dtype=np.int64)
+    fw = np.zeros(len(pos), dtype=np.uint64)
+    rc = np.zeros(len(pos), dtype=np.uint64)
+    for j in range(k):
+        c = genome[pos + j].astype(np.uint64)
+        fw = (fw << np.uint64(2)) | c
+        rc |= (np.uint64(3) - c) << np.uint64(2 * j)
+    return np.minimum(fw, rc)

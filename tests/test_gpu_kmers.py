@@ -10,26 +10,7 @@ torch = pytest.importorskip("torch")
 from kmerhash_amd import kmers as KM  # noqa: E402
 
 
-def np_kmers(seq, k, canonical):
-    """numpy statement: windows of k valid bases, first base most significant, A0 C1 G2 T3"""
-    code = np.full(256, 4, dtype=np.uint8)
-    for ch, c in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
-        code[ch] = c
-    c = code[np.asarray(seq, dtype=np.uint8)]
-    n = len(c)
-    if n < k:
-        return np.zeros(0, dtype=np.uint64)
-    valid = c < 4
-    bad = np.concatenate([[0], np.cumsum(~valid)])
-    ok = (bad[k:] - bad[: n - k + 1]) == 0
-    fw = np.zeros(n - k + 1, dtype=np.uint64)
-    rc = np.zeros(n - k + 1, dtype=np.uint64)
-    cc = (c & 3).astype(np.uint64)
-    for j in range(k):
-        fw = (fw << np.uint64(2)) | cc[j: n - k + 1 + j]
-        rc |= (np.uint64(3) - cc[j: n - k + 1 + j]) << np.uint64(2 * j)
-    out = np.minimum(fw, rc) if canonical else fw
-    return out[ok]
+from oracle.kmers_np import np_kmers  # noqa: E402  (numpy statement of the k-mer definition: test infrastructure)
 
 
 @pytest.mark.parametrize("k", [1, 5, 21, 31, 32])
@@ -102,3 +83,39 @@ def test_fasta_sequences():
     s = KM.sequences_from_fasta(fa)
     assert bytes(s) == b"\nACGTACGTNNAC\nTTTTGGGGCC"
     assert np.array_equal(KM.kmers_from_sequence(s, 4, False), np_kmers(s, 4, False))
+
+
+def _run_counter(*flags):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "benchmark", "kmer_counter.py")] + list(flags), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_kmer_counter_cycle_small():
+    """configs[4] shape on one GPU, small: FASTQ batches -> canonical 31-mers (farmhash table, capacity 128, doubling under load) ->
+    counting insert; sizes / total / 10^5 sampled counts against the prediction from the read positions; then the count / find /
+    erase / count cycle of BenchmarkKmerIndex.cpp:787-843"""
+    d = _run_counter("--reads", "60000", "--genome", "400000", "--batches", "5", "--cycle", "--verify", "--sample-ratio", "50")
+    assert d["ok"] and d["verify"]["ok"] and d["cycle"]["ok"], d
+    caps = d["capacity_per_batch_rank0"]
+    assert caps[0] > 128 and caps == sorted(caps) and caps[-1] >= 1 << 19          # grew under load, batch after batch
+    assert d["verify"]["total_kmers"] == 60000 * 120 and d["cycle"]["size_after"] < d["distinct_global"]
+
+
+def test_kmer_counter_hll_reserve():
+    d = _run_counter("--reads", "40000", "--genome", "300000", "--batches", "4", "--verify", "--hll-reserve", "--hash", "murmur3avx64")
+    assert d["ok"] and d["verify"]["ok"], d
+
+
+@pytest.mark.timeout(1800)
+def test_kmer_counter_cycle_5e8_kmers():
+    """one GPU, >= 5e8 k-mers (4.2 M reads of 150 bp, 8 file batches of 160 MB FASTQ text), farmhash, the table
+    doubling from 128 buckets under load; counts of 10^5 sampled k-mers, the total and the distinct count are checked against
+    the numpy prediction from the read positions; then the find + erase + count cycle over every 100th k-mer of a batch"""
+    d = _run_counter("--reads", "4200000", "--genome", "30000000", "--batches", "8", "--cycle", "--verify")
+    assert d["ok"] and d["verify"]["ok"] and d["cycle"]["ok"], d
+    assert d["verify"]["total_kmers"] == 4_200_000 * 120 >= 500_000_000
+    assert d["capacity_per_batch_rank0"][-1] >= 1 << 25
