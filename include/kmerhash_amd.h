@@ -55,12 +55,28 @@ typedef enum {
 
 typedef enum { KH_MEM_HOST = 0, KH_MEM_DEVICE = 1 } kh_mem;
 
+/* Key transform in front of the hash and inside key equality: fsc::TransformedHash<Key, Hash, PreTransform> together with
+ * fsc::TransformedComparator<Key, std::equal_to, PreTransform> (hash_new.hpp:387-1134; used with
+ * bliss::kmer::transform::lex_less for "bimolecule" tables in which a k-mer and its reverse complement are one key,
+ * test/unit/test_hashmap_robinhood_doubling.cpp:560-626).  The table stores the key bits of the FIRST occurrence, as the
+ * reference does; find / to_vector return the stored bits. */
+typedef enum {
+  KH_XF_IDENTITY = 0,      /* bliss::transform::identity */
+  KH_XF_DNA_LEX_LESS = 1   /* bliss::kmer::transform::lex_less on a 2-bit packed DNA k-mer (first base most significant, A0 C1 G2 T3):
+                              the key stands for min(key, reverse complement).  kmerind's own packing is not part of the reference
+                              tree: PARITY UNPINNED for the bit layout */
+} kh_key_transform;
+
 /* ---- lifetime: ctor (capacity=128, min_lf, max_lf)  hashmap_robinhood.hpp:218-233 / hashmap_linearprobe.hpp:191-206 */
 kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes /*8*/, uint32_t val_bytes /*4*/,
                     kh_hash hash, uint64_t seed /*43*/, uint64_t capacity /*128*/,
                     float min_load_factor, float max_load_factor, int device);
 kh_status kh_destroy(kh_table* t);
 kh_status kh_set_stream(kh_table* t, void* hip_stream /* hipStream_t; NULL = default stream */);
+/* the PreTransform of the table's TransformedHash / TransformedComparator; k = k-mer length (1..32) for KH_XF_DNA_LEX_LESS.
+ * Only on an empty table (the reference fixes it at compile time). */
+kh_status kh_set_key_transform(kh_table* t, kh_key_transform xf, uint32_t k);
+kh_status kh_get_key_transform(const kh_table* t, kh_key_transform* xf, uint32_t* k);
 const char* kh_last_error(const kh_table* t);
 
 /* ---- scalar state: size() :406 / capacity() :287 / load factors :261-285 / clear :413 / reserve :421 / rehash :432 */
@@ -139,6 +155,9 @@ kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]); /* RH only:
 /* ---- batched hashing: Hash::operator()(Key const*, count, out)  murmurhash3_64_avx.hpp:1584-1597, hash_new.hpp:1035-1056 */
 kh_status kh_hash_batch(kh_hash hash, uint64_t seed, const void* keys, uint64_t n, kh_mem where,
                         uint64_t* out /*[h|d]*/, int device, void* hip_stream);
+/* TransformedHash::operator()(Key const*, count, out)  hash_new.hpp:1035-1056: out[i] = hash(pre_transform(keys[i])) */
+kh_status kh_hash_batch_transformed(kh_hash hash, uint64_t seed, kh_key_transform xf, uint32_t k, const void* keys, uint64_t n,
+                                    kh_mem where, uint64_t* out /*[h|d]*/, int device, void* hip_stream);
 
 /* ---- key-space sharding for the multi-GPU layer: rank = hash(key, seed) & (p-1) (p power of two) or % p
  *      (distributed_batched_robinhood_map.hpp:513-534,632-741 assign_count_permute).  Device buffers only.
@@ -148,6 +167,10 @@ kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t nranks,
                            const uint64_t* keys_dev, const uint32_t* vals_dev /* may be NULL */, uint64_t n,
                            uint64_t* out_keys_dev /* may be NULL */, uint32_t* out_vals_dev /* may be NULL */,
                            uint64_t* counts_host, int device, void* hip_stream);
+/* the same with the distributed map's TransformedHash (rank = hash(pre_transform(key)) mod p: both strands of a k-mer go to one rank) */
+kh_status kh_shard_permute_transformed(kh_hash hash, uint64_t seed, kh_key_transform xf, uint32_t k, uint32_t nranks,
+                                       const uint64_t* keys_dev, const uint32_t* vals_dev, uint64_t n,
+                                       uint64_t* out_keys_dev, uint32_t* out_vals_dev, uint64_t* counts_host, int device, void* hip_stream);
 
 /* ---- k-mer generation front end (BenchmarkKmerCounter.cpp:1655-1706 reads sequences through kmerind's
  *      KmerParser, which is not part of the reference tree: PARITY UNPINNED, the definition below is this library's):

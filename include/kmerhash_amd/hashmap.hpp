@@ -127,12 +127,12 @@ struct hash_traits { static constexpr bool supported = false; };
 namespace fsc {
 namespace hash {
 
-#define KMERHASH_AMD_HASH_FUNCTOR(NAME, ID, SEED_T, EXPR)                                         \
+#define KMERHASH_AMD_HASH_FUNCTOR(NAME, ID, SEED_T, BATCH, EXPR)                                  \
   template <typename T> class NAME {                                                               \
    protected:                                                                                      \
     SEED_T seed;                                                                                   \
    public:                                                                                         \
-    static constexpr size_t batch_size = 1;                                                        \
+    static constexpr size_t batch_size = BATCH;                                                    \
     static constexpr kh_hash kh_id = ID;                                                           \
     using result_type = uint64_t;                                                                  \
     using argument_type = T;                                                                       \
@@ -142,23 +142,192 @@ namespace hash {
       const uint64_t k = ::kmerhash_amd::detail::key_bits(key); (void)k;                           \
       return EXPR;                                                                                 \
     }                                                                                              \
+    /* batch form Hash::operator()(T const*, count, out) (murmurhash3_64_avx.hpp:1584-1597, hash_new.hpp:1035-1056): the  \
+       keys are hashed on the GPU (kh_hash_batch), one key per lane */                                                    \
+    inline void operator()(T const* keys, size_t count, uint64_t* out) const {                     \
+      static_assert(sizeof(T) == 8, "kmerhash_amd: keys must be 8 bytes");                         \
+      if (count == 0) return;                                                                      \
+      if (kh_hash_batch(ID, uint64_t(seed), keys, count, KH_MEM_HOST, out, 0, nullptr) != KH_OK)   \
+        throw std::runtime_error("kmerhash_amd: kh_hash_batch failed (no usable MI355X / HIP runtime?)");  \
+    }                                                                                              \
   };                                                                                               \
   template <typename T> constexpr size_t NAME<T>::batch_size;                                      \
   template <typename T> constexpr kh_hash NAME<T>::kh_id;
 
 // hash_new.hpp:135-166
-KMERHASH_AMD_HASH_FUNCTOR(identity, KH_HASH_IDENTITY, uint32_t, k)
+KMERHASH_AMD_HASH_FUNCTOR(identity, KH_HASH_IDENTITY, uint32_t, 1, k)
 // hash_new.hpp:206-235 (MurmurHash3_x64_128, h[0])
-KMERHASH_AMD_HASH_FUNCTOR(murmur, KH_HASH_MURMUR3_X64_128_H0, uint32_t, ::kmerhash_amd::detail::murmur3_x64_128_h0(k, seed))
+KMERHASH_AMD_HASH_FUNCTOR(murmur, KH_HASH_MURMUR3_X64_128_H0, uint32_t, 1, ::kmerhash_amd::detail::murmur3_x64_128_h0(k, seed))
 // hash_new.hpp:218-233 (MurmurHash3_x86_128, low 64 bits)
-KMERHASH_AMD_HASH_FUNCTOR(murmur_x86, KH_HASH_MURMUR3_X86_128_LO64, uint64_t, ::kmerhash_amd::detail::murmur3_x86_128_lo64(k, uint32_t(seed)))
+KMERHASH_AMD_HASH_FUNCTOR(murmur_x86, KH_HASH_MURMUR3_X86_128_LO64, uint64_t, 1, ::kmerhash_amd::detail::murmur3_x86_128_lo64(k, uint32_t(seed)))
 // murmurhash3_64_avx.hpp:1553-1651 (same function, AVX2 batch form in the reference)
-KMERHASH_AMD_HASH_FUNCTOR(murmur3avx64, KH_HASH_MURMUR3_X86_128_LO64, uint32_t, ::kmerhash_amd::detail::murmur3_x86_128_lo64(k, seed))
+KMERHASH_AMD_HASH_FUNCTOR(murmur3avx64, KH_HASH_MURMUR3_X86_128_LO64, uint32_t, 8, ::kmerhash_amd::detail::murmur3_x86_128_lo64(k, seed))
 // hash_new.hpp:309-328 (util::Hash64WithSeed; parity unpinned)
-KMERHASH_AMD_HASH_FUNCTOR(farm, KH_HASH_FARM64, uint64_t, ::kmerhash_amd::detail::farm64_seed(k, seed))
+KMERHASH_AMD_HASH_FUNCTOR(farm, KH_HASH_FARM64, uint64_t, 1, ::kmerhash_amd::detail::farm64_seed(k, seed))
 #undef KMERHASH_AMD_HASH_FUNCTOR
 
 }  // namespace hash
+}  // namespace fsc
+
+// ---- key transforms.  The reference takes them from kmerind (bliss::transform::identity, bliss::kmer::transform::lex_less;
+// not part of the reference tree): define KMERHASH_AMD_NO_BLISS_STANDINS when the real headers are present.
+namespace kmerhash_amd {
+// 2-bit packed DNA k-mer in one 64-bit word: first base most significant, A0 C1 G2 T3 (the layout of kh_kmers_from_sequence).
+// Stands in for bliss::common::Kmer<K, DNA, uint64_t> where a k-mer TYPE is needed (lex_less needs k at compile time).
+template <unsigned K> struct dna_kmer {
+  static_assert(K >= 1 && K <= 32, "dna_kmer: 1 <= K <= 32");
+  static constexpr unsigned size = K;
+  uint64_t data;
+  dna_kmer() : data(0) {}
+  explicit dna_kmer(uint64_t d) : data(d) {}
+  uint64_t getData() const { return data; }
+  dna_kmer reverse_complement() const {
+    uint64_t x = data, r = 0;
+    for (unsigned i = 0; i < K; ++i) { r = (r << 2) | (3u - (x & 3u)); x >>= 2; }
+    return dna_kmer(r);
+  }
+  bool operator==(dna_kmer const& o) const { return data == o.data; }
+  bool operator!=(dna_kmer const& o) const { return data != o.data; }
+  bool operator<(dna_kmer const& o) const { return data < o.data; }
+};
+template <unsigned K> constexpr unsigned dna_kmer<K>::size;
+namespace detail {
+// k of a k-mer key type (Key::size, as kmerind's Kmer and dna_kmer expose it); 0 = not a k-mer type
+template <typename Key, typename = void> struct kmer_size { static constexpr unsigned value = 0; };
+template <typename Key> struct kmer_size<Key, typename std::enable_if<(Key::size > 0)>::type> { static constexpr unsigned value = Key::size; };
+inline uint64_t revcomp_bits(uint64_t x, unsigned k) { uint64_t r = 0; for (unsigned i = 0; i < k; ++i) { r = (r << 2) | (3u - (x & 3u)); x >>= 2; } return r; }
+}  // namespace detail
+}  // namespace kmerhash_amd
+#ifndef KMERHASH_AMD_NO_BLISS_STANDINS
+namespace bliss {
+namespace transform {
+template <typename T> struct identity { inline T operator()(T const& x) const { return x; } };
+}  // namespace transform
+namespace kmer { namespace transform {
+// min(k-mer, reverse complement): the canonical strand ("bimolecule" tables)
+template <typename KMER> struct lex_less {
+  static_assert(::kmerhash_amd::detail::kmer_size<KMER>::value > 0, "lex_less needs a k-mer key type that exposes its length as KMER::size");
+  inline KMER operator()(KMER const& x) const {
+    const uint64_t b = ::kmerhash_amd::detail::key_bits(x), r = ::kmerhash_amd::detail::revcomp_bits(b, ::kmerhash_amd::detail::kmer_size<KMER>::value);
+    const uint64_t m = r < b ? r : b;
+    KMER out; std::memcpy(static_cast<void*>(&out), &m, 8); return out;
+  }
+};
+} }  // namespace kmer::transform
+}  // namespace bliss
+#endif
+
+namespace kmerhash_amd {
+// maps a PreTransform instantiation to the device's key transform
+template <typename Pre, typename Key, typename = void> struct transform_traits { static constexpr bool supported = false; };
+template <typename Key> struct transform_traits< ::bliss::transform::identity<Key>, Key> {
+  static constexpr bool supported = true; static constexpr kh_key_transform xf = KH_XF_IDENTITY; static constexpr unsigned k = 0;
+};
+template <typename Key> struct transform_traits< ::bliss::kmer::transform::lex_less<Key>, Key> {
+  static constexpr bool supported = true; static constexpr kh_key_transform xf = KH_XF_DNA_LEX_LESS; static constexpr unsigned k = detail::kmer_size<Key>::value;
+};
+}  // namespace kmerhash_amd
+
+namespace fsc {
+namespace hash {
+
+// hash_new.hpp:363-374: batch_size of a functor if it has a static one, 1 otherwise
+template <class T>
+class batch_traits {
+ public:
+  template <class U = T, class = typename std::enable_if<!std::is_member_object_pointer<decltype(&U::batch_size)>::value>::type>
+  static constexpr size_t get_batch_size(int) { return U::batch_size; }
+  template <class U = T>
+  static constexpr size_t get_batch_size(...) { return 1ULL; }
+};
+
+// hash_new.hpp:387-1134: post(hash(pre(key))), single and batch forms, overloads taking std::pair<Key, V>.  On this path the
+// post-transform is the identity (the reference's benchmarks and tests use no other); the pre-transform is carried to the device
+// (kh_set_key_transform) when the functor is a map's Hash, and the batch form hashes on the device (kh_hash_batch_transformed).
+template <typename Key, template <typename> class Hash,
+          template <typename> class PreTransform = ::bliss::transform::identity,
+          template <typename> class PostTransform = ::bliss::transform::identity>
+class TransformedHash {
+ protected:
+  using PRETRANS_T = PreTransform<Key>;
+  using PRETRANS_VAL_TYPE = decltype(::std::declval<PRETRANS_T>().operator()(::std::declval<Key>()));
+  using HASH_T = Hash<PRETRANS_VAL_TYPE>;
+
+ public:
+  using HASH_VAL_TYPE = decltype(::std::declval<HASH_T>().operator()(::std::declval<PRETRANS_VAL_TYPE>()));
+  using result_type = decltype(::std::declval<PostTransform<HASH_VAL_TYPE> >().operator()(::std::declval<HASH_VAL_TYPE>()));
+  using argument_type = Key;
+
+ protected:
+  using POSTTRANS_T = PostTransform<HASH_VAL_TYPE>;
+  static_assert(std::is_same<POSTTRANS_T, ::bliss::transform::identity<HASH_VAL_TYPE> >::value,
+                "kmerhash_amd: TransformedHash supports the identity post-transform only");
+  static_assert(::kmerhash_amd::transform_traits<PRETRANS_T, Key>::supported,
+                "kmerhash_amd: PreTransform must be bliss::transform::identity or bliss::kmer::transform::lex_less");
+  static constexpr size_t lcm_(size_t a, size_t b) { return a >= b ? a : b; }     // powers of two
+
+ public:
+  static constexpr size_t pretrans_batch_size = batch_traits<PRETRANS_T>::get_batch_size(0);
+  static constexpr size_t hash_batch_size = batch_traits<HASH_T>::get_batch_size(0);
+  static constexpr size_t posttrans_batch_size = batch_traits<POSTTRANS_T>::get_batch_size(0);
+  static constexpr size_t batch_size = lcm_(lcm_(pretrans_batch_size, hash_batch_size), lcm_(posttrans_batch_size, 128UL / sizeof(HASH_VAL_TYPE)));
+  static constexpr kh_hash kh_id = HASH_T::kh_id;
+  static constexpr kh_key_transform kh_xf = ::kmerhash_amd::transform_traits<PRETRANS_T, Key>::xf;
+  static constexpr unsigned kh_k = ::kmerhash_amd::transform_traits<PRETRANS_T, Key>::k;
+
+  PRETRANS_T trans;
+  HASH_T h;
+  POSTTRANS_T posttrans;
+
+  TransformedHash(HASH_T const& _hash = HASH_T(), PRETRANS_T const& pre_trans = PRETRANS_T(), POSTTRANS_T const& post_trans = POSTTRANS_T())
+      : trans(pre_trans), h(_hash), posttrans(post_trans) {}
+  uint64_t kh_seed() const { return h.kh_seed(); }
+
+  inline result_type operator()(Key const& k) const { return posttrans(h(trans(k))); }
+  template <typename V> inline result_type operator()(::std::pair<Key, V> const& x) const { return this->operator()(x.first); }
+  template <typename V> inline result_type operator()(::std::pair<const Key, V> const& x) const { return this->operator()(x.first); }
+  // batch forms (hash_new.hpp:1035-1130)
+  inline void operator()(Key const* k, size_t const& count, result_type* out) const {
+    static_assert(sizeof(Key) == 8 && sizeof(result_type) == 8, "kmerhash_amd: 8-byte keys, 64-bit hash values");
+    if (count == 0) return;
+    if (kh_hash_batch_transformed(kh_id, kh_seed(), kh_xf, kh_k, k, count, KH_MEM_HOST, reinterpret_cast<uint64_t*>(out), 0, nullptr) != KH_OK)
+      throw std::runtime_error("kmerhash_amd: kh_hash_batch_transformed failed (no usable MI355X / HIP runtime?)");
+  }
+  template <typename V> inline void operator()(::std::pair<Key, V> const* x, size_t const& count, result_type* out) const {
+    std::vector<Key> keys; keys.reserve(count);
+    for (size_t i = 0; i < count; ++i) keys.push_back(x[i].first);
+    this->operator()(keys.data(), count, out);
+  }
+  template <typename V> inline void operator()(::std::pair<const Key, V> const* x, size_t const& count, result_type* out) const {
+    std::vector<Key> keys; keys.reserve(count);
+    for (size_t i = 0; i < count; ++i) keys.push_back(x[i].first);
+    this->operator()(keys.data(), count, out);
+  }
+};
+template <typename Key, template <typename> class Hash, template <typename> class Pre, template <typename> class Post>
+constexpr size_t TransformedHash<Key, Hash, Pre, Post>::batch_size;
+template <typename Key, template <typename> class Hash, template <typename> class Pre, template <typename> class Post>
+constexpr kh_hash TransformedHash<Key, Hash, Pre, Post>::kh_id;
+template <typename Key, template <typename> class Hash, template <typename> class Pre, template <typename> class Post>
+constexpr kh_key_transform TransformedHash<Key, Hash, Pre, Post>::kh_xf;
+template <typename Key, template <typename> class Hash, template <typename> class Pre, template <typename> class Post>
+constexpr unsigned TransformedHash<Key, Hash, Pre, Post>::kh_k;
+
+}  // namespace hash
+
+#ifndef KMERHASH_AMD_NO_BLISS_STANDINS
+// the names the reference's unit tests use (test_hashmap_robinhood_doubling.cpp:572-574; defined by kmerind there)
+template <typename Key, template <typename> class Hash, template <typename> class PreTransform = ::bliss::transform::identity,
+          template <typename> class PostTransform = ::bliss::transform::identity>
+using TransformedHash = ::fsc::hash::TransformedHash<Key, Hash, PreTransform, PostTransform>;
+// Comparator<Key> applied to the transformed keys
+template <typename Key, template <typename> class Comparator, template <typename> class Transform = ::bliss::transform::identity>
+struct TransformedComparator {
+  using transform_type = Transform<Key>;      // (stateless: the functors are created where they are applied)
+  inline bool operator()(Key const& x, Key const& y) const { return Comparator<Key>()(Transform<Key>()(x), Transform<Key>()(y)); }
+  template <typename V> inline bool operator()(::std::pair<Key, V> const& x, ::std::pair<Key, V> const& y) const { return this->operator()(x.first, y.first); }
+};
+#endif
 }  // namespace fsc
 
 namespace kmerhash_amd {
@@ -168,6 +337,13 @@ struct hash_traits<Hash, Key, typename std::enable_if<(Hash::kh_id >= 0)>::type>
   static constexpr bool supported = true;
   static kh_hash id(Hash const&) { return Hash::kh_id; }
   static uint64_t seed(Hash const& h) { return h.kh_seed(); }
+  // key transform carried by a TransformedHash (identity for the plain functors)
+  template <typename H = Hash> static constexpr auto xf_(int) -> decltype(H::kh_xf) { return H::kh_xf; }
+  template <typename H = Hash> static constexpr kh_key_transform xf_(...) { return KH_XF_IDENTITY; }
+  template <typename H = Hash> static constexpr auto k_(int) -> decltype(H::kh_k) { return H::kh_k; }
+  template <typename H = Hash> static constexpr unsigned k_(...) { return 0; }
+  static constexpr kh_key_transform xf() { return xf_<Hash>(0); }
+  static constexpr unsigned k() { return k_<Hash>(0); }
 };
 // std::hash of a 64-bit integral key is the identity in libstdc++ (the reference's default Hash)
 template <typename Key>
@@ -175,6 +351,8 @@ struct hash_traits<std::hash<Key>, Key, typename std::enable_if<std::is_integral
   static constexpr bool supported = true;
   static kh_hash id(std::hash<Key> const&) { return KH_HASH_IDENTITY; }
   static uint64_t seed(std::hash<Key> const&) { return 0; }
+  static constexpr kh_key_transform xf() { return KH_XF_IDENTITY; }
+  static constexpr unsigned k() { return 0; }
 };
 
 namespace detail {
@@ -187,7 +365,8 @@ class gpu_hashmap {
   static_assert(sizeof(T) == 4 && std::is_trivially_copyable<T>::value,
                 "kmerhash_amd: mapped type must be a 4-byte trivially copyable type");
   static_assert(hash_traits<Hash, Key>::supported,
-                "kmerhash_amd: Hash must be one of fsc::hash::{identity,murmur,murmur_x86,murmur3avx64,farm} or std::hash of a 64-bit integer");
+                "kmerhash_amd: Hash must be one of fsc::hash::{identity,murmur,murmur_x86,murmur3avx64,farm}, a fsc::hash::TransformedHash over "
+                "one of them, or std::hash of a 64-bit integer");
   // Equal must mean "same 8 key bytes" (std::equal_to<Key>, the benchmark's own ::equal_to<Kmer>, BenchmarkHashTables.cpp:169-180,
   // ...): a stateless functor is required at compile time and its behaviour is probed at construction.
   static_assert(std::is_empty<Equal>::value, "kmerhash_amd: Equal must be a stateless functor equivalent to bitwise key equality");
@@ -248,14 +427,20 @@ class gpu_hashmap {
   static Key key_from_bits(uint64_t b) { Key k; std::memcpy(static_cast<void*>(&k), &b, 8); return k; }
   void create(size_t cap, float mn, float mx) {
     h_ = nullptr;
-    {   // Equal must agree with bitwise equality (the device compares the 8 key bytes)
-      const Key a = key_from_bits(0x0123456789ABCDEFull), b = key_from_bits(0x0123456789ABCDEEull), c = key_from_bits(0x8123456789ABCDEFull);
-      if (!eq(a, a) || eq(a, b) || eq(a, c))
-        throw std::invalid_argument("kmerhash_amd: the Equal functor is not bitwise key equality");
+    const kh_key_transform xf = hash_traits<Hash, Key>::xf();
+    const unsigned xk = hash_traits<Hash, Key>::k();
+    {   // Equal must be the equality the device applies: the 8 key bytes, compared after the hash's pre-transform
+      const uint64_t abits = xk ? (0x0123456789ABCDEFull & (xk < 32 ? ((uint64_t(1) << (2 * xk)) - 1) : ~uint64_t(0))) : 0x0123456789ABCDEFull;
+      const Key a = key_from_bits(abits), b = key_from_bits(abits ^ 1), c = key_from_bits(abits ^ (xk ? 4 : 0x8000000000000000ull));
+      bool ok = eq(a, a) && !eq(a, b) && !eq(a, c);
+      if (xf == KH_XF_DNA_LEX_LESS) ok = ok && eq(a, key_from_bits(revcomp_bits(abits, xk)));
+      if (!ok) throw std::invalid_argument("kmerhash_amd: the Equal functor is not key equality under the hash's pre-transform "
+                                           "(bitwise equality; with lex_less: equality of the canonical strands)");
     }
     kh_status s = kh_create(&h_, KIND, 8, 4, hash_traits<Hash, Key>::id(hash), hash_traits<Hash, Key>::seed(hash), cap, mn, mx, 0);
     if (s != KH_OK) throw std::runtime_error("kmerhash_amd: kh_create failed with status " + std::to_string(int(s)) +
                                              " (no usable MI355X / HIP runtime?); there is no CPU fallback");
+    if (xf != KH_XF_IDENTITY) check(kh_set_key_transform(h_, xf, xk));
   }
   void touch() { snapshot_.reset(); }
 

@@ -9,13 +9,14 @@ KH_OK, KH_ERR_INVALID, KH_ERR_NOMEM, KH_ERR_FULL, KH_ERR_PROBE_OVERFLOW, KH_ERR_
 KH_KIND_ROBINHOOD, KH_KIND_LINEARPROBE = 0, 1
 KH_HASH_IDENTITY, KH_HASH_MURMUR3_X86_128_LO64, KH_HASH_MURMUR3_X64_128_H0, KH_HASH_FARM64 = 0, 1, 2, 3
 KH_MEM_HOST, KH_MEM_DEVICE = 0, 1
+KH_XF_IDENTITY, KH_XF_DNA_LEX_LESS = 0, 1
 
 STATUS_NAMES = {0: "KH_OK", 1: "KH_ERR_INVALID", 2: "KH_ERR_NOMEM", 3: "KH_ERR_FULL", 4: "KH_ERR_PROBE_OVERFLOW",
                 5: "KH_ERR_HIP", 6: "KH_ERR_UNSUPPORTED"}
 
 # every symbol include/kmerhash_amd.h declares (tests check the library exports each one)
 SYMBOLS = [
-    "kh_create", "kh_destroy", "kh_set_stream", "kh_last_error", "kh_size", "kh_capacity", "kh_get_load_thresholds",
+    "kh_create", "kh_destroy", "kh_set_stream", "kh_set_key_transform", "kh_get_key_transform", "kh_hash_batch_transformed", "kh_shard_permute_transformed", "kh_last_error", "kh_size", "kh_capacity", "kh_get_load_thresholds",
     "kh_set_min_load_factor", "kh_set_max_load_factor", "kh_get_load_factors", "kh_clear", "kh_reserve", "kh_rehash",
     "kh_insert", "kh_insert_pairs", "kh_insert_one", "kh_update", "kh_insert_reduce_plus", "kh_insert_begin", "kh_insert_feed", "kh_insert_end", "kh_count", "kh_find", "kh_find_compact", "kh_find_compact_pairs",
     "kh_erase", "kh_erase_one", "kh_to_vector", "kh_export_info", "kh_export_slots", "kh_displacement_histogram",
@@ -53,6 +54,10 @@ def lib():
     L.kh_create.argtypes = [C.POINTER(vp), i32, u32, u32, i32, u64, u64, f32, f32, i32]
     L.kh_destroy.argtypes = [vp]
     L.kh_set_stream.argtypes = [vp, vp]
+    L.kh_set_key_transform.argtypes = [vp, i32, u32]
+    L.kh_get_key_transform.argtypes = [vp, C.POINTER(i32), C.POINTER(u32)]
+    L.kh_hash_batch_transformed.argtypes = [i32, u64, i32, u32, vp, u64, i32, vp, i32, vp]
+    L.kh_shard_permute_transformed.argtypes = [i32, u64, i32, u32, u32, vp, vp, u64, vp, vp, vp, i32, vp]
     L.kh_size.argtypes = [vp, pu64]
     L.kh_capacity.argtypes = [vp, pu64]
     L.kh_get_load_thresholds.argtypes = [vp, pu64, pu64]

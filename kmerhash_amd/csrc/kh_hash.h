@@ -82,3 +82,28 @@ KH_HD uint64_t kh_hash64(uint64_t key, uint64_t seed) {
   else if (HASH == KHH_MURMUR3_X64) return kh_murmur3_x64_128_h0(key, (uint32_t)seed);
   else return kh_farm64_seed(key, seed);
 }
+
+// ---- key transform in front of the hash and inside key equality: fsc::TransformedHash<Key, Hash, PreTransform> with
+// PreTransform = bliss::kmer::transform::lex_less (hash_new.hpp:387-1134; "bimolecule" tables: a k-mer and its reverse
+// complement are ONE key, test/unit/test_hashmap_robinhood_doubling.cpp:560-626).  xk = 0: identity; xk = k (1..32): the key is a
+// 2-bit packed DNA k-mer (first base most significant, A0 C1 G2 T3) and stands for min(key, reverse complement).
+struct KhSeed {
+  uint64_t s; uint32_t xk;
+};
+KH_HD uint64_t kh_revcomp(uint64_t x, uint32_t k) {
+  x = ~x;                                                                   // complement: 3 - base
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+  x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+  x = (x >> 32) | (x << 32);
+  return x >> (64 - 2 * k);
+}
+KH_HD uint64_t kh_xf(uint64_t key, uint32_t xk) {
+  if (!xk) return key;
+  const uint64_t rc = kh_revcomp(key, xk);
+  return rc < key ? rc : key;
+}
+KH_HD bool kh_keq(uint64_t a, uint64_t b, uint32_t xk) { return xk ? kh_xf(a, xk) == kh_xf(b, xk) : a == b; }
+template <int HASH>
+KH_HD uint64_t kh_hash64(uint64_t key, KhSeed hs) { return kh_hash64<HASH>(kh_xf(key, hs.xk), hs.s); }

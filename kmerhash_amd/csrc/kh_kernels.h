@@ -63,7 +63,8 @@ template <int KIND> __device__ __forceinline__ uint32_t kh_empty_info() { return
 // Every step is one 16-byte load; consecutive buckets share a 64-byte sector three times out of four.
 // ---------------------------------------------------------------------------------------------
 template <int KIND>
-__device__ __forceinline__ uint64_t kh_find_pos(const KhSlot* __restrict__ slots, uint64_t mask, uint64_t home, uint64_t key, uint32_t* val_out = nullptr) {
+__device__ __forceinline__ uint64_t kh_find_pos(const KhSlot* __restrict__ slots, uint64_t mask, uint64_t home, uint64_t key, uint32_t* val_out = nullptr,
+                                                uint32_t xk = 0) {
   uint64_t i = home;
   if (KIND == KHK_RH) {
     // reprobe = 0x80 + distance; stop as soon as the resident entry is "richer" (or the slot is empty).
@@ -71,7 +72,7 @@ __device__ __forceinline__ uint64_t kh_find_pos(const KhSlot* __restrict__ slots
       const uint4 w = kh_slot_ld(slots + i);
       const uint32_t b = w.w & 0xFFu;
       if (reprobe > b) return KH_NONE;
-      if (reprobe == b && kh_slot_key(w) == key) { if (val_out) *val_out = w.z; return i; }
+      if (reprobe == b && kh_keq(kh_slot_key(w), key, xk)) { if (val_out) *val_out = w.z; return i; }
       i = (i + 1) & mask;
     }
     return KH_NONE;
@@ -81,7 +82,7 @@ __device__ __forceinline__ uint64_t kh_find_pos(const KhSlot* __restrict__ slots
       const uint4 w = kh_slot_ld(slots + i);
       const uint32_t b = w.w & 0xFFu;
       if (b == 0x40u) return KH_NONE;
-      if (b < 0x40u && kh_slot_key(w) == key) { if (val_out) *val_out = w.z; return i; }
+      if (b < 0x40u && kh_keq(kh_slot_key(w), key, xk)) { if (val_out) *val_out = w.z; return i; }
       i = (i + 1) & mask;
     }
     return KH_NONE;
@@ -92,7 +93,7 @@ __device__ __forceinline__ uint64_t kh_find_pos(const KhSlot* __restrict__ slots
 // batched hashing  (Hash::operator()(Key const*, count, out))
 // ---------------------------------------------------------------------------------------------
 template <int HASH>
-__global__ void k_hash_batch(const uint64_t* __restrict__ keys, uint64_t n, uint64_t seed, uint64_t* __restrict__ out) {
+__global__ void k_hash_batch(const uint64_t* __restrict__ keys, uint64_t n, KhSeed seed, uint64_t* __restrict__ out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) out[i] = kh_hash64<HASH>(keys[i], seed);
@@ -121,7 +122,7 @@ __global__ void k_hash_batch(const uint64_t* __restrict__ keys, uint64_t n, uint
 enum { KH_FIND_PERQUERY = 0, KH_FIND_COMPACT = 1, KH_FIND_PAIRS = 2, KH_FIND_COUNT = 3 };
 
 struct KhFindParams {
-  KhSlots T; const uint64_t* q; uint64_t n; uint64_t seed;
+  KhSlots T; const uint64_t* q; uint64_t n; KhSeed seed;
   uint32_t* out_vals; uint8_t* out_found;          // PERQUERY: value (hits only) + 0/1 flag per query; COUNT: out_found only
   uint64_t* out_keys; uint8_t* out_pairs16;        // COMPACT: out_keys + out_vals; PAIRS: 16-byte (key, value, 0) records
   uint32_t* ticket;                                // zero at launch
@@ -134,15 +135,24 @@ struct KhFindParams {
 // in flight together, so a chain of d slots costs ceil((d + offset) / 4) dependent memory round trips instead of d -- the
 // rounds a wave spends on the longest chain among its 256 queries (12-15 slots at load 0.8) drop from ~14 to ~4.
 #define KH_Q_W 4
-template <int KIND, int HASH>
-__device__ __forceinline__ uint32_t kh_probe_items(const KhSlots& T, const uint64_t (&key)[KH_Q_ITEMS], uint32_t valid, uint64_t seed,
-                                                   uint32_t (&val)[KH_Q_ITEMS]) {
+template <int KIND, int HASH, bool XF>
+__device__ __forceinline__ uint32_t kh_probe_items(const KhSlots& T, const uint64_t (&key)[KH_Q_ITEMS], uint32_t valid, KhSeed seed_,
+                                                   uint32_t (&val)[KH_Q_ITEMS], uint32_t* swapped = nullptr) {
+  // swapped (key transform active): bit j set when the stored key of hit j is not the query's own bit pattern but its
+  // equivalent under the transform (the reverse complement): find returns the STORED pair (hashmap_robinhood.hpp:1194-1268)
+  // XF = false: the table has no key transform -- the compiler drops every trace of it from the hot kernel
+  const KhSeed seed = KhSeed{seed_.s, XF ? seed_.xk : 0u};
   const uint64_t mask = T.cap - 1;
-  uint32_t hit = 0;
+  const uint32_t xk = seed.xk;
+  uint32_t hit = 0, swp = 0;
   if (T.cap < KH_Q_W) {                                // tables of 1 or 2 buckets: slot by slot
 #pragma unroll
     for (int j = 0; j < KH_Q_ITEMS; ++j)
-      if ((valid >> j) & 1u) { if (kh_find_pos<KIND>(T.s, mask, kh_hash64<HASH>(key[j], seed) & mask, key[j], &val[j]) != KH_NONE) hit |= 1u << j; }
+      if ((valid >> j) & 1u) {
+        const uint64_t at = kh_find_pos<KIND>(T.s, mask, kh_hash64<HASH>(key[j], seed) & mask, key[j], &val[j], xk);
+        if (at != KH_NONE) { hit |= 1u << j; if (xk && T.s[at].key != key[j]) swp |= 1u << j; }
+      }
+    if (swapped) *swapped = swp;
     return hit;
   }
   uint64_t base[KH_Q_ITEMS];                           // first slot of the sector being looked at
@@ -172,10 +182,10 @@ __device__ __forceinline__ uint32_t kh_probe_items(const KhSlots& T, const uint6
           if (KIND == KHK_RH) {
             const uint32_t reprobe = 0x80u + dist[j] + (uint32_t)s - first[j];
             if (reprobe > b || reprobe > 0xFFu) active &= ~(1u << j);                               // richer resident or empty: absent
-            else if (reprobe == b && kh_slot_key(w[j][s]) == key[j]) { hit |= 1u << j; val[j] = w[j][s].z; active &= ~(1u << j); }
+            else if (reprobe == b && kh_keq(kh_slot_key(w[j][s]), key[j], xk)) { hit |= 1u << j; val[j] = w[j][s].z; active &= ~(1u << j); if (xk && kh_slot_key(w[j][s]) != key[j]) swp |= 1u << j; }
           } else {
             if (b == 0x40u) active &= ~(1u << j);
-            else if (b < 0x40u && kh_slot_key(w[j][s]) == key[j]) { hit |= 1u << j; val[j] = w[j][s].z; active &= ~(1u << j); }
+            else if (b < 0x40u && kh_keq(kh_slot_key(w[j][s]), key[j], xk)) { hit |= 1u << j; val[j] = w[j][s].z; active &= ~(1u << j); if (xk && kh_slot_key(w[j][s]) != key[j]) swp |= 1u << j; }
           }
         }
       }
@@ -191,10 +201,11 @@ __device__ __forceinline__ uint32_t kh_probe_items(const KhSlots& T, const uint6
       }
     }
   }
+  if (swapped) *swapped = swp;
   return hit;
 }
 
-template <int KIND, int HASH, int OUT>
+template <int KIND, int HASH, int OUT, bool XF>
 __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_wcnt[KH_Q_NB * KH_Q_ITEMS][KH_Q_THREADS / 64];
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
     // the tile is probed in KH_Q_NB batches of KH_Q_ITEMS queries per lane; one look-back per tile ranks all of them.  The
     // batch loop stays rolled (the registers of a batch -- 4 sectors of 4 slots per lane -- are reused by the next one); the
     // values of the hits wait in LDS
-    uint32_t hit = 0;                                        // bit b * KH_Q_ITEMS + j
+    uint32_t hit = 0, swapped = 0;                           // bit b * KH_Q_ITEMS + j
 #pragma unroll 1
     for (int b = 0; b < KH_Q_NB; ++b) {
       uint64_t key[KH_Q_ITEMS]; uint32_t v[KH_Q_ITEMS];
@@ -233,8 +244,10 @@ __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
         if (i < P.n) { key[j] = P.q[i]; valid |= 1u << j; }
       }
       if (!__any(valid != 0)) continue;                      // (the last tile may end early)
-      const uint32_t h = kh_probe_items<KIND, HASH>(P.T, key, valid, P.seed, v);
+      uint32_t sw = 0;
+      const uint32_t h = kh_probe_items<KIND, HASH, XF>(P.T, key, valid, P.seed, v, XF ? &sw : nullptr);
       hit |= h << (b * KH_Q_ITEMS);
+      swapped |= sw << (b * KH_Q_ITEMS);
       if (OUT == KH_FIND_PERQUERY || OUT == KH_FIND_COUNT) {
 #pragma unroll
         for (int j = 0; j < KH_Q_ITEMS; ++j) {
@@ -315,7 +328,8 @@ __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
 #pragma unroll
     for (int j = 0; j < KH_Q_NB * KH_Q_ITEMS; ++j) {
       if ((hit >> j) & 1u) {
-        const uint64_t key = P.q[base + (uint64_t)j * KH_Q_THREADS + tid];
+        uint64_t key = P.q[base + (uint64_t)j * KH_Q_THREADS + tid];
+        if (XF && ((swapped >> j) & 1u)) key = kh_revcomp(key, P.seed.xk);        // the table holds the other strand's bit pattern
         const unsigned long long o = obase + before[j];
         if (OUT == KH_FIND_PAIRS) {
           uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = s_val[j * KH_Q_THREADS + tid]; w.w = 0;
@@ -334,14 +348,14 @@ __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
 // LP: tombstone in place (info = 0x80), hashmap_linearprobe.hpp:911-978.
 // A key listed twice in the batch erases once: the atomic decides who counts it.
 template <int KIND, int HASH>
-__global__ __launch_bounds__(KH_Q_THREADS) void k_erase_mark(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, uint64_t seed,
+__global__ __launch_bounds__(KH_Q_THREADS) void k_erase_mark(KhSlots T, const uint64_t* __restrict__ q, uint64_t n, KhSeed seed,
                                                           unsigned long long* __restrict__ n_erased) {
   const uint64_t mask = T.cap - 1;
   const uint64_t stride = (uint64_t)gridDim.x * KH_Q_THREADS;
   uint32_t mine = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * KH_Q_THREADS + threadIdx.x; i < n; i += stride) {
     const uint64_t key = q[i];
-    const uint64_t pos = kh_find_pos<KIND>(T.s, mask, kh_hash64<HASH>(key, seed) & mask, key);
+    const uint64_t pos = kh_find_pos<KIND>(T.s, mask, kh_hash64<HASH>(key, seed) & mask, key, nullptr, seed.xk);
     if (pos == KH_NONE) continue;
     if (KIND == KHK_RH) {
       const uint32_t old = atomicOr(&T.s[pos].info, KH_INFO_ERASE_MARK);
@@ -513,7 +527,7 @@ struct KhPartParams {
   const KhTile* tiles;                     // null: arithmetic tiles of KH_PART_TILE over [0,n), seg 0
   const uint32_t* ntiles_dev;              // with tiles: actual tile count
   uint32_t ntiles;                         // without tiles: tile count
-  uint64_t seed;
+  KhSeed seed;
   uint32_t PB;                             // total partition bits
   uint32_t shift;                          // digit = (q >> shift) & (nb-1)
   uint32_t nb;                             // bins in this pass (power of two, <= 2048)
@@ -690,7 +704,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
 // launch per slice sweeps all keys and counts the ones whose id falls into its slice (two sweeps for 1.25e8 keys per GPU cost
 // 0.6 ms; the two-level fallback histogram costs 1.9 ms there).
 template <int HASH>
-__global__ __launch_bounds__(KH_FULLHIST_THREADS) void k_part_hist_full(const char* __restrict__ kbase, uint32_t kstride, uint64_t n, uint64_t seed,
+__global__ __launch_bounds__(KH_FULLHIST_THREADS) void k_part_hist_full(const char* __restrict__ kbase, uint32_t kstride, uint64_t n, KhSeed seed,
                                                                          uint32_t PB, uint32_t slice, uint32_t slice_bits,
                                                                          uint32_t* __restrict__ counts /* [2^PB], zeroed */) {
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];     // 2^(PB - slice_bits) / 2 words
@@ -842,28 +856,44 @@ enum { KH_DEDUP_FIRST = 0, KH_DEDUP_LAST = 1, KH_DEDUP_PLUS = 2 };
 // (the index is the high word), max = last value wins, add = std::plus on the value.  Returns the bit mask of this
 // lane's records (x = it * KH_CHUNK_THREADS + tid) that are representatives.  ns <= KH_DD_M < KH_HS entries: the probe
 // always finds an empty entry.  Caller: set[] zeroed and records staged before (barrier), barrier after.
-__device__ __forceinline__ uint32_t kh_dd_fold(const unsigned long long* lk, unsigned long long* liv, uint32_t* set, uint32_t ns, int mode) {
+__device__ __forceinline__ uint32_t kh_dd_fold(unsigned long long* lk, unsigned long long* liv, uint32_t* set, uint32_t ns, int mode, uint32_t xk = 0) {
   const uint32_t tid = threadIdx.x;
   uint32_t rep_mask = 0;
+  uint32_t rep_of[KH_DD_M / KH_CHUNK_THREADS];
   for (uint32_t x0 = 0, it = 0; x0 < ns; x0 += KH_CHUNK_THREADS, ++it) {
     const uint32_t x = x0 + tid;
+    if (it < KH_DD_M / KH_CHUNK_THREADS) rep_of[it] = 0xFFFFFFFFu;
     if (x < ns) {
       const unsigned long long key = lk[x];
-      uint32_t slot = (uint32_t)kh_fmix64(key + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
+      // (key transform: a k-mer and its reverse complement are one key -- they must meet in the same set entry)
+      uint32_t slot = (uint32_t)kh_fmix64(kh_xf(key, xk) + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
       for (;;) {
         // one LDS round trip per probe: the CAS itself tells whether the entry was free (most are: load <= 0.37)
         const uint32_t cur = atomicCAS(&set[slot], 0u, x + 1u);
         if (cur == 0) { rep_mask |= 1u << it; break; }
         const uint32_t rep = cur - 1u;
-        if (lk[rep] == key) {
+        if (kh_keq(lk[rep], key, xk)) {
           const unsigned long long iv = liv[x];
           if (mode == KH_DEDUP_FIRST) atomicMin(&liv[rep], iv);
           else if (mode == KH_DEDUP_LAST) atomicMax(&liv[rep], iv);
           else atomicAdd(&liv[rep], iv & 0xFFFFFFFFull);
+          if (it < KH_DD_M / KH_CHUNK_THREADS) rep_of[it] = rep;
           break;
         }
         slot = (slot + 1) & (KH_HS - 1);
       }
+    }
+  }
+  if (xk && mode == KH_DEDUP_FIRST) {
+    // first value wins, and so does the first KEY: the element stored is the bit pattern of the earliest occurrence (the
+    // reference inserts one by one and never replaces a key).  The winner of a group is the record whose (position | value)
+    // word survived the min; where that is not the representative itself it hands its key over.  (lk[] of a representative is
+    // only compared under the transform, which the hand-over does not change.)
+    __syncthreads();
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      const uint32_t x = it * KH_CHUNK_THREADS + tid;
+      if (x < ns && rep_of[it] != 0xFFFFFFFFu && liv[rep_of[it]] == liv[x]) lk[rep_of[it]] = lk[x];
     }
   }
   return rep_mask;
@@ -927,7 +957,7 @@ struct KhDedupParams {
   uint64_t* nk; uint32_t* nv;                                    // outputs, written at src.merged_off[q] + j
   uint32_t* cnt_new;                                             // [nparts]
   unsigned long long* max_idx_plus1;                             // max (first-occurrence index + 1) over new keys
-  KhSlots T; uint64_t seed;
+  KhSlots T; KhSeed seed;
   // speculative fusion of the chunk-count step (empty table, one partition == one chunk of capacity count_cap):
   // home-bucket counts and the chunk's (max,+) summary are produced here and k_chunk_count is skipped when the
   // capacity decided after this kernel equals count_cap
@@ -1003,7 +1033,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
         // ---- fold duplicates into their representative; rep_mask: which of this lane's records are representatives
         for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
         __syncthreads();
-        rep_mask = kh_dd_fold(lk, liv, set, ns, P.mode);
+        rep_mask = kh_dd_fold(lk, liv, set, ns, P.mode, P.seed.xk);
         __syncthreads();
         if (pos >= m) break;                       // stream exhausted: the representatives are this class's distinct keys
         // ---- compact the representatives to the front (set[] is free again: scratch), then continue with the stream
@@ -1041,7 +1071,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           uint32_t cur_val = 0;
           if (!P.table_empty) {
             const uint64_t h = kh_hash64<HASH>(key, P.seed);
-            at = kh_find_pos<KIND>(P.T.s, mask, h & mask, key, &cur_val);
+            at = kh_find_pos<KIND>(P.T.s, mask, h & mask, key, &cur_val, P.seed.xk);
           }
           if (P.mode == KH_DEDUP_LAST) { if (at != KH_NONE) P.T.s[at].val = (uint32_t)iv; }   // kh_update's assign pass: store the LAST value
           else if (P.mode == KH_DEDUP_PLUS && at != KH_NONE) P.T.s[at].val = cur_val + (uint32_t)iv;   // one lane per distinct key: no race
@@ -1118,7 +1148,7 @@ struct KhRebuildParams {
   const uint64_t* noff;              // [nparts+1] start of every partition's list in ck/cv (null: no new elements)
   const uint32_t* ncnt;              // per-partition list length; null: lists are dense (length = noff[q+1]-noff[q])
   uint32_t PB;                       // partition bits the new elements were grouped with
-  uint64_t seed;
+  KhSeed seed;
   uint16_t* homecnt;                 // [New.cap] elements per home bucket
   long long* sumA; long long* sumN;  // per-chunk (max,+) summary, absolute positions
   const long long* xcarry;           // per-chunk carry-in (absolute first free position)
@@ -1381,7 +1411,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_chunk_place(KhRebuildParam
 #define KH_FSPILL 128u           // run-over slots staged in LDS by the fused kernel
 struct KhFusedParams {
   KhSrcSet src; uint32_t PB;
-  KhSlots New; uint64_t seed; int mode;                  // KH_DEDUP_FIRST or KH_DEDUP_PLUS
+  KhSlots New; KhSeed seed; int mode;                  // KH_DEDUP_FIRST or KH_DEDUP_PLUS
   unsigned long long* pub;                               // [nch] zero-initialised: bit63 valid | run-over << 32 | count
   uint64_t* ck0; uint32_t* cv0; uint16_t* homecnt0;      // chunk 0 parked here: distinct keys/values (KH_DD_M), home counts (KH_L)
   uint32_t* maxidx;                                      // [nch] per chunk: max(first-occurrence index + 1) (k_fused_totals reduces)
@@ -1567,7 +1597,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     if (V.n > 1) __syncthreads();       // the source table (in simg[]) has been read by every lane
     for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
     __syncthreads();
-    rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
+    rep_mask = kh_dd_fold(lk, liv, set, m, P.mode, P.seed.xk);
     __syncthreads();
   } else if (SRC == 2) {
     // ---- insert into a non-empty table: the chunk's current elements + the batch's records of this chunk, folded together
@@ -1604,7 +1634,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     if (V.n > 1) __syncthreads();
     for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
     __syncthreads();
-    rep_mask = kh_dd_fold(lk, liv, set, m, P.mode);
+    rep_mask = kh_dd_fold(lk, liv, set, m, P.mode, P.seed.xk);
     __syncthreads();
   } else {
     m = kh_stage_from_table<KIND, HASH, false>(P.R, c, Sc, lk, liv, &s_x, &s_max);
@@ -1821,12 +1851,12 @@ __global__ void k_unpack_slots(const KhSlot* __restrict__ slots, uint64_t cap, u
 #define KH_SHARD_TILE (KH_SHARD_THREADS * 8)     // 8 consecutive items per lane; fewer, larger tiles keep the [rank][tile] offset scan short
 #define KH_SHARD_MAXR 64
 template <int HASH>
-__device__ __forceinline__ uint32_t kh_rank_of(uint64_t key, uint64_t seed, uint32_t p, uint32_t pmask) {
+__device__ __forceinline__ uint32_t kh_rank_of(uint64_t key, KhSeed seed, uint32_t p, uint32_t pmask) {
   uint64_t h = kh_hash64<HASH>(key, seed);
   return pmask ? (uint32_t)(h & pmask) : (uint32_t)(h % p);
 }
 template <int HASH>
-__global__ void k_shard_count(const uint64_t* __restrict__ keys, uint64_t n, uint64_t seed, uint32_t p, uint32_t pmask,
+__global__ void k_shard_count(const uint64_t* __restrict__ keys, uint64_t n, KhSeed seed, uint32_t p, uint32_t pmask,
                               uint32_t* __restrict__ tile_counts /* [p][ntiles] */, uint32_t ntiles) {
   __shared__ uint32_t h[KH_SHARD_MAXR];
   if (threadIdx.x < KH_SHARD_MAXR) h[threadIdx.x] = 0;
@@ -1859,7 +1889,7 @@ __global__ void k_shard_count(const uint64_t* __restrict__ keys, uint64_t n, uin
   if (threadIdx.x < p) tile_counts[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 template <int HASH>
-__global__ void k_shard_scatter(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n, uint64_t seed,
+__global__ void k_shard_scatter(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n, KhSeed seed,
                                 uint32_t p, uint32_t pmask, const uint64_t* __restrict__ tile_off /* [p][ntiles] exclusive */,
                                 uint32_t ntiles, uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
   // stable: lane t owns items [8t, 8t+8) of the tile; per rank, an exclusive scan over lanes gives the order
@@ -1903,7 +1933,7 @@ __global__ void k_shard_scatter(const uint64_t* __restrict__ keys, const uint32_
 // order) so that the write-out is coalesced.  Stable, like the generic kernel.
 template <int HASH>
 __global__ __launch_bounds__(KH_SHARD_THREADS) void k_shard_scatter8(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n,
-                                                          uint64_t seed, uint32_t p, uint32_t pmask,
+                                                          KhSeed seed, uint32_t p, uint32_t pmask,
                                                           const uint64_t* __restrict__ tile_off /* [p][ntiles] exclusive */,
                                                           uint32_t ntiles, uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
   __shared__ uint64_t lk[KH_SHARD_TILE];
@@ -1976,7 +2006,7 @@ __global__ __launch_bounds__(KH_SHARD_THREADS) void k_shard_scatter8(const uint6
 // Registers are accumulated per workgroup in LDS (precision <= 13) and merged with global atomicMax.
 // ---------------------------------------------------------------------------------------------
 template <int HASH, bool FROM_KEYS>
-__global__ void k_hll_update(const uint64_t* __restrict__ in, uint64_t n, uint64_t seed, uint32_t precision, uint32_t ignored,
+__global__ void k_hll_update(const uint64_t* __restrict__ in, uint64_t n, KhSeed seed, uint32_t precision, uint32_t ignored,
                              uint32_t* __restrict__ regs, int use_lds) {
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
   const uint32_t m = 1u << precision;
@@ -2092,7 +2122,7 @@ __global__ __launch_bounds__(256) void k_fastq_mask(const uint8_t* __restrict__ 
 enum { KH_SMALL_FIRST = 0, KH_SMALL_UPDATE = 1, KH_SMALL_PLUS = 2, KH_SMALL_ERASE = 3 };
 template <int KIND, int HASH>
 __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_t kstride, const char* __restrict__ vbase, uint32_t vstride,
-                              uint32_t vconst, uint32_t n, int op, uint64_t seed, unsigned long long* __restrict__ out /* [0] new/erased, [1] keys done */,
+                              uint32_t vconst, uint32_t n, int op, KhSeed seed, unsigned long long* __restrict__ out /* [0] new/erased, [1] keys done */,
                               uint32_t* __restrict__ flags) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   const uint64_t mask = T.cap - 1;
@@ -2111,7 +2141,7 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
         const uint4 w = kh_slot_ld(S + p);
         const uint32_t inf = w.w & 0xFFu;
         if (inf < reprobe) break;
-        if (inf == reprobe && kh_slot_key(w) == key) { found = true; break; }
+        if (inf == reprobe && kh_keq(kh_slot_key(w), key, seed.xk)) { found = true; break; }
         ++reprobe; p = (p + 1) & mask;
         if (reprobe > 0xFFu) break;
       }
@@ -2168,7 +2198,7 @@ __global__ void k_small_batch(KhSlots T, const char* __restrict__ kbase, uint32_
         const uint32_t inf = w.w & 0xFFu;
         if (inf == 0x40u) { if (ins == KH_NONE) ins = p; break; }
         if (inf >= 0x80u) { if (ins == KH_NONE) ins = p; }
-        else if (kh_slot_key(w) == key) { found = true; break; }
+        else if (kh_keq(kh_slot_key(w), key, seed.xk)) { found = true; break; }
         p = (p + 1) & mask;
       }
       if (found) {
@@ -2272,7 +2302,7 @@ __device__ __forceinline__ int kh_rh_insert_absent(KhSlot* S, uint64_t mask, uin
 // Robin Hood erase by backward shift (hashmap_robinhood.hpp:1294-1356).  Pass 1 finds the key and the end of the shift (the
 // first slot behind it that is empty or holds an element at its home); pass 2 moves the elements in between one slot down.
 template <bool BOUNDED>
-__device__ __forceinline__ int kh_rh_erase_one(KhSlot* S, uint64_t mask, uint64_t home, uint64_t key, uint64_t reg_start) {
+__device__ __forceinline__ int kh_rh_erase_one(KhSlot* S, uint64_t mask, uint64_t home, uint64_t key, uint64_t reg_start, uint32_t xk) {
   uint64_t at = 0, len = 0;                               // slot of the key; elements to move
   {
     uint64_t p0 = home;
@@ -2289,7 +2319,7 @@ __device__ __forceinline__ int kh_rh_erase_one(KhSlot* S, uint64_t mask, uint64_
           const uint32_t inf = w[j].w & 0xFFu;
           if (state == 0) {
             if (inf < r) return KH_IP_ABSENT;
-            if (inf == r && kh_slot_key(w[j]) == key) { at = (p0 + j) & mask; state = 1; }
+            if (inf == r && kh_keq(kh_slot_key(w[j]), key, xk)) { at = (p0 + j) & mask; state = 1; }
             else { ++r; if (r > 0xFFu) return KH_IP_ABSENT; }
           } else {
             if (inf <= 0x80u) state = 2; else ++len;
@@ -2314,7 +2344,7 @@ __device__ __forceinline__ int kh_rh_erase_one(KhSlot* S, uint64_t mask, uint64_
 }
 
 struct KhInplaceParams {
-  KhSlots T; uint64_t seed;
+  KhSlots T; KhSeed seed;
   uint32_t ofs;                            // region r = slots [r * KH_IP_L + ofs, (r + 1) * KH_IP_L + ofs), circular
   // the input list, one of: (key, value) records | key / value arrays (in_v null: values 0) | the per-partition lists
   // k_dedup wrote (list q: part_cnt[q] entries of in_k / in_v from part_off[q] on; one workgroup per partition)
@@ -2377,7 +2407,7 @@ __global__ void k_ip_apply(KhInplaceParams P) {
       const ulonglong2 rec = P.bins[(uint64_t)r * KH_IP_CAP + j];
       const uint64_t home = kh_hash64<HASH>(rec.x, P.seed) & mask;
       const int st = OP == KH_IP_INSERT ? kh_rh_insert_absent<true>(P.T.s, mask, home, rec.x, (uint32_t)rec.y, reg_start)
-                                        : kh_rh_erase_one<true>(P.T.s, mask, home, rec.x, reg_start);
+                                        : kh_rh_erase_one<true>(P.T.s, mask, home, rec.x, reg_start, P.seed.xk);
       if (st == KH_IP_DONE) ++done;
       else if (st == KH_IP_LEAVES_REGION) P.defer[atomicAdd(P.n_defer, 1ull)] = rec;
       else if (st == KH_IP_TOO_FAR) atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u);
@@ -2398,7 +2428,7 @@ __global__ void k_ip_serial(KhInplaceParams P) {
     const ulonglong2 rec = P.in_rec[i];
     const uint64_t home = kh_hash64<HASH>(rec.x, P.seed) & mask;
     const int st = OP == KH_IP_INSERT ? kh_rh_insert_absent<false>(P.T.s, mask, home, rec.x, (uint32_t)rec.y, 0)
-                                      : kh_rh_erase_one<false>(P.T.s, mask, home, rec.x, 0);
+                                      : kh_rh_erase_one<false>(P.T.s, mask, home, rec.x, 0, P.seed.xk);
     if (st == KH_IP_DONE) ++done;
     else if (st == KH_IP_TOO_FAR) atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u);
   }

@@ -114,7 +114,7 @@ struct Block { char* p; size_t cap; };
 
 struct kh_table {
   int kind, hash, device;
-  uint64_t seed;
+  KhSeed seed;      // storage hash seed + key transform (kh_set_key_transform)
   hipStream_t stream;
   float min_lf, max_lf;
   uint64_t min_load, max_load, lsize;
@@ -1083,12 +1083,17 @@ kh_status launch_find(kh_table* t, int out_mode, const uint64_t* q, uint64_t n, 
   const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ntiles, (uint64_t)ncu * 8));
   const char* name = out_mode == KH_FIND_COUNT ? "k_count" : "k_find";
   { Launch L(t, name);
+#define KH_FIND_LAUNCH(OUT)                                                                                                            \
+    if (t->seed.xk) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, OUT, true>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); }   \
+    else { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, OUT, false>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); }
     switch (out_mode) {
-      case KH_FIND_PERQUERY: KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, KH_FIND_PERQUERY>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); break;
-      case KH_FIND_COMPACT: KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, KH_FIND_COMPACT>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); break;
-      case KH_FIND_PAIRS: KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, KH_FIND_PAIRS>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); break;
-      default: KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_find<KIND, HASH, KH_FIND_COUNT>), dim3(grid), dim3(KH_Q_THREADS), 0, t->stream, F)); break;
-    } }
+      case KH_FIND_PERQUERY: KH_FIND_LAUNCH(KH_FIND_PERQUERY) break;
+      case KH_FIND_COMPACT: KH_FIND_LAUNCH(KH_FIND_COMPACT) break;
+      case KH_FIND_PAIRS: KH_FIND_LAUNCH(KH_FIND_PAIRS) break;
+      default: KH_FIND_LAUNCH(KH_FIND_COUNT) break;
+    }
+#undef KH_FIND_LAUNCH
+  }
   HIPCHK(hipGetLastError());
   if (hits_dev) *hits_dev = ctl;
   return KH_OK;
@@ -1236,7 +1241,7 @@ kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t v
   if (device < 0 || device >= ndev) return KH_ERR_INVALID;
   if (hipSetDevice(device) != hipSuccess) return KH_ERR_HIP;
   kh_table* t = new kh_table();
-  t->kind = (int)kind; t->hash = (int)hash; t->device = device; t->seed = seed; t->stream = nullptr;
+  t->kind = (int)kind; t->hash = (int)hash; t->device = device; t->seed = KhSeed{seed, 0u}; t->stream = nullptr;
   t->min_lf = min_lf; t->max_lf = max_lf; t->lsize = 0;
   t->cur = kNoSlots; t->spare = t->cur;
   t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false;
@@ -1547,10 +1552,34 @@ kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]) {
   return KH_OK;
 }
 
+}  // extern "C"
+namespace {
+inline bool xform_ok(kh_key_transform xf, uint32_t k) { return xf == KH_XF_IDENTITY || (xf == KH_XF_DNA_LEX_LESS && k >= 1 && k <= 32); }
+inline KhSeed make_seed(uint64_t seed, kh_key_transform xf, uint32_t k) { return KhSeed{seed, xf == KH_XF_DNA_LEX_LESS ? k : 0u}; }
+}
+extern "C" {
+kh_status kh_set_key_transform(kh_table* t, kh_key_transform xf, uint32_t k) {
+  if (!t) return KH_ERR_INVALID;
+  if (!xform_ok(xf, k)) return fail(t, KH_ERR_INVALID, "unknown key transform / k outside 1..32");
+  if (t->lsize != 0 || t->ins.active) return fail(t, KH_ERR_INVALID, "the key transform can only be set on an empty table");
+  t->seed.xk = xf == KH_XF_DNA_LEX_LESS ? k : 0u;
+  return KH_OK;
+}
+kh_status kh_get_key_transform(const kh_table* t, kh_key_transform* xf, uint32_t* k) {
+  if (!t) return KH_ERR_INVALID;
+  if (xf) *xf = t->seed.xk ? KH_XF_DNA_LEX_LESS : KH_XF_IDENTITY;
+  if (k) *k = t->seed.xk;
+  return KH_OK;
+}
 kh_status kh_hash_batch(kh_hash hash, uint64_t seed, const void* keys, uint64_t n, kh_mem where, uint64_t* out, int device, void* stream_) {
+  return kh_hash_batch_transformed(hash, seed, KH_XF_IDENTITY, 0, keys, n, where, out, device, stream_);
+}
+kh_status kh_hash_batch_transformed(kh_hash hash, uint64_t seed_, kh_key_transform xf, uint32_t k, const void* keys, uint64_t n, kh_mem where,
+                                    uint64_t* out, int device, void* stream_) {
   kh_table* t = nullptr;
   if (n == 0) return KH_OK;
-  if (!keys || !out || (int)hash < 0 || (int)hash > 3) return KH_ERR_INVALID;
+  if (!keys || !out || (int)hash < 0 || (int)hash > 3 || !xform_ok(xf, k)) return KH_ERR_INVALID;
+  const KhSeed seed = make_seed(seed_, xf, k);
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(device));
   const uint64_t* dk = static_cast<const uint64_t*>(keys);
@@ -1570,8 +1599,14 @@ kh_status kh_hash_batch(kh_hash hash, uint64_t seed, const void* keys, uint64_t 
 
 kh_status kh_shard_permute(kh_hash hash, uint64_t seed, uint32_t p, const uint64_t* keys, const uint32_t* vals, uint64_t n,
                            uint64_t* out_keys, uint32_t* out_vals, uint64_t* counts_host, int device, void* stream_) {
+  return kh_shard_permute_transformed(hash, seed, KH_XF_IDENTITY, 0, p, keys, vals, n, out_keys, out_vals, counts_host, device, stream_);
+}
+kh_status kh_shard_permute_transformed(kh_hash hash, uint64_t seed_, kh_key_transform xf, uint32_t k, uint32_t p, const uint64_t* keys,
+                                       const uint32_t* vals, uint64_t n, uint64_t* out_keys, uint32_t* out_vals, uint64_t* counts_host,
+                                       int device, void* stream_) {
   kh_table* t = nullptr;
-  if (p == 0 || p > KH_SHARD_MAXR || !counts_host || (int)hash < 0 || (int)hash > 3) return KH_ERR_INVALID;
+  if (p == 0 || p > KH_SHARD_MAXR || !counts_host || (int)hash < 0 || (int)hash > 3 || !xform_ok(xf, k)) return KH_ERR_INVALID;
+  const KhSeed seed = make_seed(seed_, xf, k);
   for (uint32_t r = 0; r < p; ++r) counts_host[r] = 0;
   if (n == 0) return KH_OK;
   if (!keys || (out_keys && vals && !out_vals)) return KH_ERR_INVALID;
@@ -1723,9 +1758,9 @@ static kh_status hll_update(kh_hll* h, const void* in, uint64_t n, kh_mem where,
   const size_t smem = use_lds ? (sizeof(uint32_t) << h->precision) : 0;
   const uint32_t grid = grid_for(n, 256, 1024);
   if (from_keys) {
-    KH_SWITCH_HASH(h->hash, hipLaunchKernelGGL((k_hll_update<HASH, true>), dim3(grid), dim3(256), smem, h->stream, d, n, h->seed, h->precision, h->ignored, h->regs, use_lds));
+    KH_SWITCH_HASH(h->hash, hipLaunchKernelGGL((k_hll_update<HASH, true>), dim3(grid), dim3(256), smem, h->stream, d, n, KhSeed{h->seed, 0u}, h->precision, h->ignored, h->regs, use_lds));
   } else {
-    hipLaunchKernelGGL((k_hll_update<KHH_IDENTITY, false>), dim3(grid), dim3(256), smem, h->stream, d, n, h->seed, h->precision, h->ignored, h->regs, use_lds);
+    hipLaunchKernelGGL((k_hll_update<KHH_IDENTITY, false>), dim3(grid), dim3(256), smem, h->stream, d, n, KhSeed{h->seed, 0u}, h->precision, h->ignored, h->regs, use_lds);
   }
   hipError_t e = hipGetLastError();
   if (tmp) { if (e == hipSuccess) e = hipStreamSynchronize(h->stream); pool_free(h->device, tmp); }

@@ -152,6 +152,12 @@ class _HashMapBase:
         self._chk(self._L.kh_get_load_factors(self._h, None, C.byref(c), None))
         return c.value
 
+    def set_key_transform(self, k):
+        """PreTransform of fsc::TransformedHash / TransformedComparator (hash_new.hpp:387-1134): k = 0 identity, k = 1..32
+        bliss::kmer::transform::lex_less on 2-bit packed DNA k-mers -- a k-mer and its reverse complement are one key
+        ("bimolecule" tables); the bits stored are those of the first occurrence.  Only on an empty table."""
+        self._chk(self._L.kh_set_key_transform(self._h, K.KH_XF_DNA_LEX_LESS if k else K.KH_XF_IDENTITY, int(k)))
+
     def clear(self):
         self._chk(self._L.kh_clear(self._h))
 
@@ -351,8 +357,9 @@ class hashmap_linearprobe_doubling(_HashMapBase):
     DEFAULT_MAX_LF = 0.6
 
 
-def hash_batch(keys, hash="murmur3avx64", seed=43, device=0):
-    """Hash::operator()(Key const*, count, out): batched 64-bit hashing on the GPU."""
+def hash_batch(keys, hash="murmur3avx64", seed=43, device=0, lex_less_k=0):
+    """Hash::operator()(Key const*, count, out): batched 64-bit hashing on the GPU; lex_less_k = k: TransformedHash with the
+    lex_less pre-transform on 2-bit packed DNA k-mers (hash of min(k-mer, reverse complement))."""
     L = K.lib()
     kb = _Buf(keys, np.uint64, 8)
     if kb.where == K.KH_MEM_DEVICE:
@@ -363,7 +370,8 @@ def hash_batch(keys, hash="murmur3avx64", seed=43, device=0):
         out = np.zeros(kb.n, dtype=np.uint64)
         optr = out.ctypes.data
         stream = None
-    st = L.kh_hash_batch(_hash_id(hash), seed, kb.ptr, kb.n, kb.where, optr, device, stream)
+    st = L.kh_hash_batch_transformed(_hash_id(hash), seed, K.KH_XF_DNA_LEX_LESS if lex_less_k else K.KH_XF_IDENTITY, int(lex_less_k),
+                                     kb.ptr, kb.n, kb.where, optr, device, stream)
     if st != K.KH_OK:
-        raise KhError(st, "kh_hash_batch")
+        raise KhError(st, "kh_hash_batch_transformed")
     return out

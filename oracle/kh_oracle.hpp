@@ -216,6 +216,21 @@ static inline size_t load_threshold(size_t buckets, float lf) {
 
 typedef std::pair<uint64_t, uint32_t> value_type;
 
+// ---- PreTransform of fsc::TransformedHash / fsc::TransformedComparator (hash_new.hpp:387-1134): the tables hash
+// pre(key) and call two keys equal when pre(a) == pre(b); what is stored is the inserted key itself.  xk = 0: identity;
+// xk = k: bliss::kmer::transform::lex_less on a 2-bit packed DNA k-mer (first base most significant, A0 C1 G2 T3) --
+// kmerind's packing is absent from the reference tree, so the bit layout is this library's (parity unpinned).
+static inline uint64_t revcomp_kmer(uint64_t x, uint32_t k) {
+  uint64_t r = 0;
+  for (uint32_t i = 0; i < k; ++i) { r = (r << 2) | (3u - (x & 3u)); x >>= 2; }
+  return r;
+}
+static inline uint64_t pre_transform(uint64_t key, uint32_t xk) {
+  if (!xk) return key;
+  const uint64_t rc = revcomp_kmer(key, xk);
+  return rc < key ? rc : key;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Robin Hood table  (hashmap_robinhood.hpp)
 // ---------------------------------------------------------------------------------------------
@@ -241,7 +256,9 @@ class RobinHood {
     set_min_load_factor(min_lf);
     set_max_load_factor(max_lf);
   }
-  uint64_t hash(uint64_t k) const { return hash_u64(hash_id, k, seed); }
+  uint32_t xk = 0;      // key transform (0 = identity)
+  uint64_t hash(uint64_t k) const { return hash_u64(hash_id, pre_transform(k, xk), seed); }
+  bool equal(uint64_t a, uint64_t b) const { return pre_transform(a, xk) == pre_transform(b, xk); }
   void set_min_load_factor(float f) { min_load_factor = f; min_load = load_threshold(buckets, f); }  // :261
   void set_max_load_factor(float f) { max_load_factor = f; max_load = load_threshold(buckets, f); }  // :267
   size_t size() const { return lsize; }
@@ -288,7 +305,7 @@ class RobinHood {
         if (reprobe == EMPTY) { container[i] = vv; break; }
         std::swap(container[i], vv);
       } else if (reprobe == info[i]) {
-        if (!success && container[i].first == vv.first) {  // :594
+        if (!success && equal(container[i].first, vv.first)) {  // :594
           insert_pos = i; success = false; probe_count = j;
           break;
         }
@@ -316,7 +333,7 @@ class RobinHood {
     for (size_t j = 0; j < buckets; ++j) {
       if (reprobe > info[i]) break;
       else if (reprobe == info[i]) {
-        if (k == container[i].first) { result = i; break; }
+        if (equal(k, container[i].first)) { result = i; break; }
       }
       ++reprobe;
       i = (i + 1) & mask;
@@ -393,7 +410,9 @@ class LinearProbe {
     set_min_load_factor(min_lf);
     set_max_load_factor(max_lf);
   }
-  uint64_t hash(uint64_t k) const { return hash_u64(hash_id, k, seed); }
+  uint32_t xk = 0;      // key transform (0 = identity)
+  uint64_t hash(uint64_t k) const { return hash_u64(hash_id, pre_transform(k, xk), seed); }
+  bool equal(uint64_t a, uint64_t b) const { return pre_transform(a, xk) == pre_transform(b, xk); }
   void set_min_load_factor(float f) { min_load_factor = f; min_load = load_threshold(buckets, f); }
   void set_max_load_factor(float f) { max_load_factor = f; max_load = load_threshold(buckets, f); }
   size_t size() const { return lsize; }
@@ -438,13 +457,13 @@ class LinearProbe {
     for (i = pos; i < buckets; ++i) {
       if (info[i] == EMPTY) { insert_pos = i; break; }
       if (info[i] == DELETED && insert_pos == buckets) insert_pos = i;
-      else if (is_normal(info[i]) && key == container[i].first) return std::make_pair(i, false);
+      else if (is_normal(info[i]) && equal(key, container[i].first)) return std::make_pair(i, false);
     }
     if (i == buckets) {
       for (i = 0; i < pos; ++i) {
         if (info[i] == EMPTY) { insert_pos = i; break; }
         if (info[i] == DELETED && insert_pos == buckets) insert_pos = i;
-        else if (is_normal(info[i]) && key == container[i].first) return std::make_pair(i, false);
+        else if (is_normal(info[i]) && equal(key, container[i].first)) return std::make_pair(i, false);
       }
     }
     if (insert_pos == buckets)
@@ -467,12 +486,12 @@ class LinearProbe {
     size_t pos = hash(k) % buckets, i;
     for (i = pos; i < buckets; ++i) {
       if (info[i] == EMPTY) break;
-      if (is_normal(info[i]) && k == container[i].first) return i;
+      if (is_normal(info[i]) && equal(k, container[i].first)) return i;
     }
     if (i == buckets) {
       for (i = 0; i < pos; ++i) {
         if (info[i] == EMPTY) break;
-        if (is_normal(info[i]) && k == container[i].first) return i;
+        if (is_normal(info[i]) && equal(k, container[i].first)) return i;
       }
     }
     return std::numeric_limits<size_t>::max();

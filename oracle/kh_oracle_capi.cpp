@@ -36,6 +36,11 @@ void* ora_create(int kind, uint64_t capacity, float min_lf, float max_lf, int ha
   else t->lp = new LinearProbe(capacity, min_lf, max_lf, hash_id, seed);
   return t;
 }
+void ora_set_key_transform(void* h, uint32_t xk) {      // only on an empty table
+  Table* t = static_cast<Table*>(h);
+  if (t->kind == 0) t->rh->xk = xk; else t->lp->xk = xk;
+}
+uint64_t ora_pre_transform(uint64_t key, uint32_t xk) { return pre_transform(key, xk); }
 void ora_destroy(void* h) {
   Table* t = static_cast<Table*>(h);
   delete t->rh; delete t->lp; delete t;

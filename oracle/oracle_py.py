@@ -52,6 +52,10 @@ def lib():
         L.ora_load_threshold.restype = C.c_uint64
         L.ora_load_threshold.argtypes = [C.c_uint64, C.c_float]
         L.ora_create.restype = C.c_void_p
+        L.ora_set_key_transform.argtypes = [C.c_void_p, C.c_uint32]
+        L.ora_set_key_transform.restype = None
+        L.ora_pre_transform.argtypes = [C.c_uint64, C.c_uint32]
+        L.ora_pre_transform.restype = C.c_uint64
         L.ora_create.argtypes = [C.c_int, C.c_uint64, C.c_float, C.c_float, C.c_int, C.c_uint64]
         L.ora_destroy.argtypes = [C.c_void_p]
         for f in ("ora_size", "ora_capacity", "ora_max_load", "ora_min_load"):
@@ -149,6 +153,10 @@ class _TableBase:
 
     def min_load(self):
         return int(self._f("min_load")(self.h))
+
+    def set_key_transform(self, k):
+        """PreTransform = lex_less on 2-bit packed DNA k-mers of length k (0: identity); only on an empty table"""
+        self._L.ora_set_key_transform(self.h, int(k))
 
     def set_min_load_factor(self, f):
         self._f("set_min_load_factor")(self.h, f)

@@ -112,6 +112,63 @@ void differential(const char* name, size_t n, bool is_rh) {
   std::printf("%s ok (n=%zu, distinct=%zu)\n", name, n, gold.size());
 }
 
+// The reference's bimolecule-mode test (test/unit/test_hashmap_robinhood_doubling.cpp:560-626 with Transform = lex_less):
+//   THash = fsc::TransformedHash<Kmer, Hash, Transform>, Equal1 = fsc::TransformedComparator<Kmer, std::equal_to, Transform>,
+//   gold = std::unordered_map<Kmer, uint32_t, THash, Equal1>; sorted to_vector() of both must be equal: a k-mer and its
+//   reverse complement are one key, the bits stored are those of the first occurrence.
+template <template <typename, typename, typename, typename, typename> class MAP, unsigned K, template <typename> class Hash>
+void bimolecule(const char* name, size_t n) {
+  using Kmer = kmerhash_amd::dna_kmer<K>;
+  using THash = ::fsc::TransformedHash<Kmer, Hash, ::bliss::kmer::transform::lex_less>;
+  using Equal1 = ::fsc::TransformedComparator<Kmer, std::equal_to, ::bliss::kmer::transform::lex_less>;
+  using Map = MAP<Kmer, uint32_t, THash, Equal1, ::std::allocator<::std::pair<Kmer, uint32_t> > >;
+  static_assert(::fsc::hash::batch_traits<THash>::get_batch_size(0) == THash::batch_size && THash::batch_size == 16, "batch_traits sees TransformedHash::batch_size");
+  static_assert(::fsc::hash::batch_traits<::fsc::hash::murmur3avx64<Kmer> >::get_batch_size(0) == 8, "murmur3avx64 hashes 8 keys per AVX2 batch in the reference");
+  static_assert(::fsc::hash::batch_traits<std::equal_to<Kmer> >::get_batch_size(0) == 1, "no batch_size member: 1");
+  std::default_random_engine gen(K);
+  const uint64_t top = K < 32 ? ((uint64_t(1) << (2 * K)) - 1) : ~uint64_t(0);
+  std::uniform_int_distribution<uint64_t> dist(0, top);
+  std::vector<std::pair<Kmer, uint32_t> > input;
+  std::unordered_map<Kmer, uint32_t, THash, Equal1> gold;
+  for (size_t i = 0; i < n; ++i) {
+    Kmer k(dist(gen));
+    if (i % 3 == 1) k = input[gen() % input.size()].first.reverse_complement();      // the other strand of an earlier k-mer
+    if (i % 7 == 3) k = input[gen() % input.size()].first;                           // an exact repeat
+    input.push_back(std::make_pair(k, uint32_t(i)));
+    gold.emplace(k, uint32_t(i));
+  }
+  Map map;
+  map.set_min_load_factor(0.35f);
+  map.set_max_load_factor(0.8f);
+  map.insert(input);
+  auto cmp = [](std::pair<Kmer, uint32_t> const& x, std::pair<Kmer, uint32_t> const& y) { return x.first == y.first ? x.second < y.second : x.first < y.first; };
+  std::vector<std::pair<Kmer, uint32_t> > test_vals = map.to_vector(), gold_vals(gold.begin(), gold.end());
+  CHECK(test_vals.size() == gold_vals.size() && gold_vals.size() < n);
+  std::sort(test_vals.begin(), test_vals.end(), cmp);
+  std::sort(gold_vals.begin(), gold_vals.end(), cmp);
+  CHECK(std::equal(test_vals.begin(), test_vals.end(), gold_vals.begin()));
+  // either strand finds the stored pair
+  std::vector<Kmer> q;
+  for (size_t i = 0; i < std::min<size_t>(n, 3000); ++i) q.push_back(i % 2 ? input[i].first.reverse_complement() : input[i].first);
+  auto found = map.find(q.begin(), q.end());
+  auto counts = map.count(q.begin(), q.end());
+  CHECK(found.size() == q.size());
+  for (size_t i = 0; i < q.size(); ++i) { auto it = gold.find(q[i]); CHECK(counts[i] == 1 && it != gold.end() && found[i].first == it->first && found[i].second == it->second); }
+  CHECK(map.find(q[1]) != map.end() && map.find(q[1])->first == gold.find(q[1])->first);
+  // the batch form of the functor (device) == its single-key form (host)
+  THash th;
+  std::vector<uint64_t> hv(q.size());
+  th(q.data(), q.size(), hv.data());
+  for (size_t i = 0; i < q.size(); ++i) CHECK(hv[i] == th(q[i]) && hv[i] == th(q[i].reverse_complement()));
+  // erase by the other strand
+  std::vector<Kmer> e;
+  for (size_t i = 0; i < 500; ++i) e.push_back(input[i].first.reverse_complement());
+  size_t ne = map.erase(e.begin(), e.end());
+  for (auto& k : e) gold.erase(k);
+  CHECK(map.size() == gold.size() && ne > 0);
+  std::printf("%s ok (n=%zu, distinct under lex_less=%zu)\n", name, n, gold.size() + ne);
+}
+
 int main() {
   differential<fsc::hashmap_robinhood_doubling, uint64_t, fsc::hash::murmur3avx64<uint64_t> >("rh/u64/murmur3avx64", 100000, true);
   differential<fsc::hashmap_robinhood_doubling, uint64_t, std::hash<uint64_t> >("rh/u64/std::hash", 20000, true);
@@ -128,6 +185,20 @@ int main() {
     for (size_t i = 0; i < k.size(); ++i) CHECK(out[i] == h(k[i]));
     CHECK(h(uint64_t(1)) == 0xdbcde6617f85bf2aull);
     CHECK(fsc::hash::murmur<uint64_t>(43)(uint64_t(1)) == 0x252c590efc7e7503ull);
+  }
+  bimolecule<fsc::hashmap_robinhood_doubling, 31, fsc::hash::farm>("rh/dna_kmer<31>/TransformedHash<farm, lex_less>", 60000);
+  bimolecule<fsc::hashmap_robinhood_doubling, 21, fsc::hash::murmur3avx64>("rh/dna_kmer<21>/TransformedHash<murmur3avx64, lex_less>", 20000);
+  bimolecule<fsc::hashmap_linearprobe_doubling, 31, fsc::hash::murmur>("lp/dna_kmer<31>/TransformedHash<murmur, lex_less>", 20000);
+  {  // TransformedHash with the identity pre-transform is the plain functor; std::equal_to does not fit a lex_less hash
+    using TH = fsc::hash::TransformedHash<uint64_t, fsc::hash::farm>;
+    fsc::hashmap_robinhood_doubling<uint64_t, uint32_t, TH> m;
+    m.insert(uint64_t(5), 7u);
+    CHECK(m.find(uint64_t(5))->second == 7u && TH()(uint64_t(5)) == fsc::hash::farm<uint64_t>()(uint64_t(5)));
+    bool threw = false;
+    using K31 = kmerhash_amd::dna_kmer<31>;
+    try { fsc::hashmap_robinhood_doubling<K31, uint32_t, fsc::TransformedHash<K31, fsc::hash::farm, bliss::kmer::transform::lex_less>, std::equal_to<K31> > bad; }
+    catch (std::invalid_argument&) { threw = true; }
+    CHECK(threw);
   }
   {  // an Equal functor that is not bitwise equality is refused at construction
     bool threw = false;

@@ -907,3 +907,64 @@ def test_mid_size_in_place_region_boundaries(oracle):
     assert g.erase(dev(e)) == o.erase(e)
     check_state(g, o, 0)
     g.close()
+
+
+def _revcomp(x, k):
+    r = np.zeros_like(x)
+    y = x.copy()
+    for _ in range(k):
+        r = (r << np.uint64(2)) | (np.uint64(3) - (y & np.uint64(3)))
+        y >>= np.uint64(2)
+    return r
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+@pytest.mark.parametrize("k", [31, 21, 32])
+def test_bimolecule_tables_key_transform(oracle, kname, cls, kind, k):
+    """SURVEY 8 row a20: fsc::TransformedHash<Kmer, Hash, lex_less> + TransformedComparator (hash_new.hpp:387-1134) as the reference's
+    tests instantiate the maps in bimolecule mode (test_hashmap_robinhood_doubling.cpp:560-626): a k-mer and its reverse complement
+    are ONE key, hashed and compared as min(k-mer, reverse complement); what is stored -- and what find / to_vector return -- are the
+    bits of the first occurrence.  Every path: bulk build, insert into a non-empty table, general path, small and mid-size batches in
+    place, update, reducer, erase, queries."""
+    rng = np.random.default_rng(k)
+    top = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    fw = W.distinct_u64(60_000, seed=k) & top
+    rc = _revcomp(fw, k)
+    g = cls(128, 0.35, 0.8, hash="farm", seed=43); o = oracle.OracleTable(kind, 128, 0.35, 0.8, 3, 43)
+    g.set_key_transform(k); o.set_key_transform(k)
+    # both strands of many k-mers in one batch, either strand first; duplicates
+    keys = np.concatenate([fw[:30_000], rc[10_000:40_000], fw[20_000:50_000]])
+    keys = keys[rng.permutation(len(keys))]
+    vals = np.arange(len(keys), dtype=np.uint32)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals)
+    check_state(g, o, kind)                              # sorted (stored key, value) sets equal: the FIRST occurrence's bits are stored
+    assert g.size() < len(np.unique(keys))               # strands were merged
+    q = np.concatenate([fw[:2000], rc[:2000], rc[45_000:47_000], fw[55_000:56_000], rc[55_000:56_000]])
+    check_queries(g, o, q)                               # find returns the stored pair, whichever strand is asked for
+    # second batch into the non-empty table (fused insert), then the general path, then in place
+    k2 = np.concatenate([rc[40_000:60_000], fw[:5000]]); v2 = np.arange(len(k2), dtype=np.uint32) + np.uint32(7)
+    assert g.insert(dev(k2), dev(v2)) == o.insert(k2, v2)
+    check_state(g, o, kind)
+    extra = W.distinct_u64(3000, seed=1000 + k) & top
+    for batch in (np.concatenate([extra[:5], _revcomp(extra[:5], k)]), np.concatenate([extra[5:300], _revcomp(extra[100:300], k)])):
+        bv = np.arange(len(batch), dtype=np.uint32) + np.uint32(99)
+        assert g.insert(dev(batch), dev(bv)) == o.insert(batch, bv)
+        check_state(g, o, kind)
+    u = np.concatenate([rc[:300], extra[300:600]]); uv = np.arange(len(u), dtype=np.uint32) + np.uint32(5000)
+    g.update(dev(u), dev(uv))
+    for kk, vv in zip(u.tolist(), uv.tolist()):
+        o.update_one(kk, vv)
+    check_state(g, o, kind)
+    e = np.concatenate([rc[100:4000], fw[3000:9000], extra[:10]])
+    assert g.erase(dev(e)) == o.erase(e)
+    check_state(g, o, kind)
+    check_queries(g, o, q)
+    for x in (int(fw[20_000]), int(rc[20_001])):
+        assert g.erase_one(x) == o.erase_one(x)
+    check_state(g, o, kind)
+    with pytest.raises(kh.KhError):
+        g.set_key_transform(0)                           # not on a non-empty table
+    # batched TransformedHash::operator()
+    h = kh.hash_batch(q, "farm", 43, lex_less_k=k)
+    assert np.array_equal(h, kh.hash_batch(np.minimum(q, _revcomp(q, k)), "farm", 43))
+    g.close()
