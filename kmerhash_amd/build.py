@@ -11,6 +11,11 @@ LIB = os.path.join(HERE, "libkmerhash_amd.so")
 RES = os.path.join(HERE, "kernel_resources.json")      # per-kernel registers / LDS / occupancy reported by the compiler
 
 
+DIST_SRC = os.path.join(HERE, "csrc", "kmerhash_amd_dist.cpp")
+DIST_LIB = os.path.join(HERE, "libkmerhash_amd_dist.so")
+DIST_DEPS = [DIST_SRC, os.path.join(HERE, "..", "include", "kmerhash_amd_dist.h"), os.path.join(HERE, "..", "include", "kmerhash_amd.h")]
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if c and os.path.exists(c):
@@ -43,6 +48,23 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+def build_dist_library(force=False, verbose=False):
+    """libkmerhash_amd_dist.so: the sharded table over RCCL (host-only C++ on top of the C-ABI library and librccl)."""
+    build_library()
+    if not force and os.path.exists(DIST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(DIST_LIB) for d in DIST_DEPS + [LIB] if os.path.exists(d)):
+        return DIST_LIB
+    cmd = [hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-value", "-Wno-unused-result", "-o", DIST_LIB, DIST_SRC, "-L" + HERE, "-lkmerhash_amd", "-lrccl",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    p = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
+    if p.returncode != 0 or verbose:
+        print(p.stderr)
+    if p.returncode != 0:
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+    return DIST_LIB
+
+
 def _write_resources(remarks):
     """kernel_resources.json: {mangled kernel name: {"VGPRs":..,"LDS":..,"Occupancy":..,"Scratch":..}} from the compiler's
     -Rpass-analysis=kernel-resource-usage remarks (tests/test_kernel_resources.py guards the occupancy-critical kernels)"""
@@ -68,3 +90,4 @@ def _write_resources(remarks):
 
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_dist_library(force=True, verbose=True))
