@@ -1422,6 +1422,7 @@ struct KhFusedParams {
   unsigned long long* est;                               // [0] distinct so far << 32 | records so far (ONE word: the pair must be
                                                          //     read consistently), [1] abort
   uint32_t* flags;
+  long long poll_limit;                                  // cycles the look-back may wait for its predecessor (~4 ms; a test hook shortens it)
   KhRebuildParams R;                                     // SRC == 1 only: source table, erase mask, new distinct elements
 };
 
@@ -1724,7 +1725,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     for (;;) {
       w = __hip_atomic_load(&P.pub[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (w & VALID) break;
-      if (clock64() - t0 > (1ll << 23)) { atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u); w = VALID; break; }   // bounded: ~4 ms, then general path
+      if (clock64() - t0 > P.poll_limit) { atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u); w = VALID; break; }   // bounded: ~4 ms, then general path
       __builtin_amdgcn_s_sleep(4);
     }
     const uint32_t x = (uint32_t)((w >> 32) & 0x7FFFFFFFu);

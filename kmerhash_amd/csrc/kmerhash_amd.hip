@@ -314,6 +314,55 @@ struct PreCount { uint16_t* homecnt; long long* sumA; long long* sumN; };   // c
 
 const bool g_disable_fused_rebuild = getenv("KH_DISABLE_FUSED_BUILD") != nullptr || getenv("KH_DISABLE_FUSED_REBUILD") != nullptr;   // test hooks
 
+// The three speculative one-launch forms share their launch sequence: k_build_fused<KIND, HASH, SRC> over all chunks, the
+// reduction of the per-chunk totals, and the tail launch that places chunk 0 once the last chunk's run-over is known.
+// SRC 0: bulk build into an empty table from partition records; 1: re-layout of the current table (+ new distinct lists);
+// 2: current table + partition records folded together.  Returns with the stream synchronised and, in t->hpin,
+// [0] elements placed, [1] max(first-occurrence position + 1), bytes 32..: the vote words, bytes 64..: the flags.
+const long long g_poll_limit = getenv("KH_DEBUG_POLL_LIMIT") ? atoll(getenv("KH_DEBUG_POLL_LIMIT")) : (1ll << 23);     // test hook: look-back time-out
+struct FusedRun { unsigned long long* totals; uint32_t* flags; };
+kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw, uint32_t PB_tail, const char* name, FusedRun* out) {
+  const uint32_t nch = (uint32_t)(nw.cap >> KH_LB);
+  char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
+  const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
+  TAKE(blk, char, sz_all);
+  TAKE(maxidx, uint32_t, nch);
+  TAKE(ck0, uint64_t, KH_DD_M); TAKE(cv0, uint32_t, KH_DD_M); TAKE(hc0, uint16_t, KH_L); TAKE(xc0, long long, 1);
+  TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
+  HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
+  HIPCHK(hipMemsetAsync(maxidx, 0, sizeof(uint32_t) * nch, t->stream));
+  F.New = nw; F.seed = t->seed;
+  F.pub = reinterpret_cast<unsigned long long*>(blk);
+  unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);   // 2 x u64 (k_fused_totals)
+  F.maxidx = maxidx; F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
+  F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);          // 2 x u64
+  F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);                  // KH_NFLAGS x u32
+  F.poll_limit = g_poll_limit;
+  F.R.New = nw; F.R.seed = t->seed; F.R.flags = F.flags;
+  { Launch L(t, name);
+    if (src == 0) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 0>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    else if (src == 1) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    else { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); } }
+  { Launch L(t, "k_fused_totals");
+    hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
+  { // chunk 0: placed now that the last chunk's run-over is known (one workgroup of the general placement kernel)
+    Launch L(t, "k_fused_tail");
+    hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);
+    HIPCHK(hipMemsetAsync(noff0, 0, 16, t->stream));
+    HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));      // list length of partition 0 = count field of pub[0]
+    KhRebuildParams T0;
+    memset(&T0, 0, sizeof(T0));
+    T0.Old = kNoSlots; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB_tail;
+    T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  out->totals = totals; out->flags = F.flags;
+  return KH_OK;
+}
+
 kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint32_t* cv, const uint64_t* noff,
                   const uint32_t* ncnt, uint32_t PB, bool drop_marked, uint64_t total_after, const PreCount* pre = nullptr) {
   if (total_after > new_cap)
@@ -333,43 +382,14 @@ kh_status rebuild(kh_table* t, uint64_t new_cap, const uint64_t* ck, const uint3
       (from_empty ? noff != nullptr
                   : (t->cur.cap >= 2 * (uint64_t)KH_L && (new_cap == t->cur.cap || new_cap == 2 * t->cur.cap)))) {
     const size_t keep_blk = t->blk, keep_off = t->off;
-    char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
-    const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
-    TAKE(blk, char, sz_all);
-    TAKE(maxidx, uint32_t, nch);
-    TAKE(ck0, uint64_t, KH_DD_M); TAKE(cv0, uint32_t, KH_DD_M); TAKE(hc0, uint16_t, KH_L); TAKE(xc0, long long, 1);
-    TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
-    HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
-    HIPCHK(hipMemsetAsync(maxidx, 0, sizeof(uint32_t) * nch, t->stream));
     KhFusedParams F;
     memset(&F, 0, sizeof(F));
-    F.PB = PB; F.New = nw; F.seed = t->seed; F.mode = KH_DEDUP_FIRST;
-    F.pub = reinterpret_cast<unsigned long long*>(blk);
-    unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);
-    F.maxidx = maxidx; F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
-    F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);
-    F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);
-    F.R.Old = t->cur; F.R.drop_marked = drop_marked ? 1 : 0; F.R.New = nw; F.R.ck = ck; F.R.cv = cv; F.R.noff = noff; F.R.ncnt = ncnt; F.R.PB = PB;
+    F.PB = PB; F.mode = KH_DEDUP_FIRST;
+    F.R.Old = t->cur; F.R.drop_marked = drop_marked ? 1 : 0; F.R.ck = ck; F.R.cv = cv; F.R.noff = noff; F.R.ncnt = ncnt; F.R.PB = PB;
     if (from_empty) F.R.Old.cap = 0;     // nothing to carry over: the source scan is skipped
-    F.R.seed = t->seed; F.R.flags = F.flags;
-    { Launch L(t, "k_rebuild_fused");
-      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
-    { Launch L(t, "k_fused_totals");
-      hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
-    { Launch L(t, "k_fused_tail");
-      hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);
-      HIPCHK(hipMemsetAsync(noff0, 0, 16, t->stream));
-      HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
-      KhRebuildParams T0;
-      memset(&T0, 0, sizeof(T0));
-      T0.Old = kNoSlots; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0;
-      T0.PB = log2u(new_cap >> KH_LB);       // the parked list is chunk 0's own: one partition per chunk
-      T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
-      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
-    HIPCHK(hipStreamSynchronize(t->stream));
+    FusedRun run;
+    // (the parked list of chunk 0 is its own: one partition per chunk)
+    { kh_status fs = launch_fused(t, 1, F, nw, log2u(new_cap >> KH_LB), "k_rebuild_fused", &run); if (fs != KH_OK) return fs; }
     const uint32_t* ff = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 64);
     bool bad = false;
     for (int i = 0; i < KH_NFLAGS; ++i) bad = bad || ff[i] != 0;
@@ -603,46 +623,17 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     KhSlots nw;
     st = fresh_slots(t, cap_u, nw);
     if (st != KH_OK) return st;
-    char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
-    const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
-    TAKE(blk, char, sz_all);
-    TAKE(maxidx, uint32_t, nch);
-    TAKE(ck0, uint64_t, KH_DD_M); TAKE(cv0, uint32_t, KH_DD_M); TAKE(hc0, uint16_t, KH_L); TAKE(xc0, long long, 1);
-    TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
-    HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
     KhFusedParams F;
-    F.src = S; F.PB = PB; F.New = nw; F.seed = t->seed;
+    memset(&F, 0, sizeof(F));
+    F.src = S; F.PB = PB;
     F.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST;
-    F.pub = reinterpret_cast<unsigned long long*>(blk);
-    unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);   // 2 x u64 (k_fused_totals)
-    F.maxidx = maxidx;
-    F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
-    F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);          // 2 x u64
-    F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);                  // KH_NFLAGS x u32
-    memset(&F.R, 0, sizeof(F.R));
     F.base_size = 0;
     F.n_total = n;
     // giving up early only makes sense if a smaller capacity is possible at all (an insert never shrinks the table)
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
-    { Launch L(t, "k_build_fused");
-      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 0>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
-    { Launch L(t, "k_fused_totals");
-      hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
-    { // chunk 0: placed now that the last chunk's run-over is known (one workgroup of the general placement kernel)
-      Launch L(t, "k_fused_tail");
-      hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);
-      HIPCHK(hipMemsetAsync(noff0, 0, 16, t->stream));
-      // list length of partition 0 = count field of pub[0]
-      HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
-      KhRebuildParams T0;
-      memset(&T0, 0, sizeof(T0));
-      T0.Old = kNoSlots; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
-      T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
-      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
-    HIPCHK(hipStreamSynchronize(t->stream));
+    FusedRun run;
+    { kh_status fs = launch_fused(t, 0, F, nw, PB, "k_build_fused", &run); if (fs != KH_OK) return fs; }
+    unsigned long long* totals = run.totals;
     const uint64_t fd = t->hpin[0];
     const uint64_t flast = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
     const uint32_t* ff = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 64);
@@ -687,45 +678,17 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     KhSlots nw;
     st = fresh_slots(t, cap_u, nw);
     if (st != KH_OK) return st;
-    char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
-    const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
-    TAKE(blk, char, sz_all);
-    TAKE(maxidx, uint32_t, nch);
-    TAKE(ck0, uint64_t, KH_DD_M); TAKE(cv0, uint32_t, KH_DD_M); TAKE(hc0, uint16_t, KH_L); TAKE(xc0, long long, 1);
-    TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
-    HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
-    HIPCHK(hipMemsetAsync(maxidx, 0, sizeof(uint32_t) * nch, t->stream));
     KhFusedParams F;
     memset(&F, 0, sizeof(F));
-    F.src = S; F.PB = PB; F.New = nw; F.seed = t->seed;
+    F.src = S; F.PB = PB;
     F.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST;
-    F.pub = reinterpret_cast<unsigned long long*>(blk);
-    unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);
-    F.maxidx = maxidx; F.ck0 = ck0; F.cv0 = cv0; F.homecnt0 = hc0;
-    F.est = reinterpret_cast<unsigned long long*>(blk + sz_pub + 32);
-    F.flags = reinterpret_cast<uint32_t*>(blk + sz_pub + 64);
     F.n_total = n;
     F.base_size = t->lsize;
     // giving up early only makes sense if the smaller capacity is possible at all (an insert never shrinks the table)
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
-    F.R.Old = t->cur; F.R.New = nw; F.R.PB = PB; F.R.seed = t->seed; F.R.flags = F.flags;
-    { Launch L(t, "k_insert_fused");
-      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
-    { Launch L(t, "k_fused_totals");
-      hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
-    { Launch L(t, "k_fused_tail");
-      hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);
-      HIPCHK(hipMemsetAsync(noff0, 0, 16, t->stream));
-      HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));
-      KhRebuildParams T0;
-      memset(&T0, 0, sizeof(T0));
-      T0.Old = kNoSlots; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB;
-      T0.seed = t->seed; T0.homecnt = hc0; T0.xcarry = xc0; T0.flags = F.flags;
-      KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_chunk_place<KIND, HASH>), dim3(1), dim3(KH_CHUNK_THREADS), 0, t->stream, T0));
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
-    HIPCHK(hipStreamSynchronize(t->stream));
+    F.R.Old = t->cur; F.R.PB = PB;
+    FusedRun run;
+    { kh_status fs = launch_fused(t, 2, F, nw, PB, "k_insert_fused", &run); if (fs != KH_OK) return fs; }
     const uint64_t total = t->hpin[0];
     const uint64_t fd = total >= t->lsize ? total - t->lsize : 0;
     const uint64_t flast = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);

@@ -968,3 +968,31 @@ def test_bimolecule_tables_key_transform(oracle, kname, cls, kind, k):
     h = kh.hash_batch(q, "farm", 43, lex_less_k=k)
     assert np.array_equal(h, kh.hash_batch(np.minimum(q, _revcomp(q, k)), "farm", 43))
     g.close()
+
+
+def test_fused_build_look_back_time_out_falls_back_to_the_general_path():
+    """k_build_fused waits (bounded) for its predecessor workgroup's published run-over; a time-out raises a flag and the
+    host redoes the batch on the general path.  KH_DEBUG_POLL_LIMIT=0 makes every look-back that does not find the word at its first
+    read give up: the results must still be the oracle's, through k_dedup / k_chunk_place."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, kmerhash_amd as kh\n"
+            "from kmerhash_amd import workloads as W\n"
+            "from oracle import oracle_py as O\n"
+            "k = W.distinct_u64(3000000, seed=78); v = np.arange(len(k), dtype=np.uint32)\n"
+            "g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8); g.profile_enable(True)\n"
+            "o = O.OracleTable(0, 128, 0.35, 0.8)\n"
+            "assert g.insert(k, v) == o.insert(k, v)\n"
+            "p = g.profile(); assert 'k_build_fused' in p and 'k_dedup' in p and 'k_chunk_place' in p, p\n"
+            "assert np.array_equal(g.export_info(), o.export_info()) and g.capacity() == o.capacity()\n"
+            "a, b = g.sorted_items(), o.sorted_items(); assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])\n"
+            "k2 = W.distinct_u64(1000000, seed=79); v2 = np.arange(len(k2), dtype=np.uint32)\n"
+            "assert g.insert(k2, v2) == o.insert(k2, v2)          # fused insert into the non-empty table: same time-out, same fall-back\n"
+            "assert g.erase(k[:500000]) == o.erase(k[:500000])    # one-launch re-layout: likewise\n"
+            "assert np.array_equal(g.export_info(), o.export_info())\n"
+            "a, b = g.sorted_items(), o.sorted_items(); assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])\n"
+            "print('time-out path ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KH_DEBUG_POLL_LIMIT="0"), capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "time-out path ok" in r.stdout, r.stdout + r.stderr
