@@ -534,6 +534,12 @@ struct KhPartParams {
   uint32_t* counts;                        // [nseg*nb] histogram (hist kernel)
   unsigned long long* cursor;              // [nseg*nb] running output offsets (scatter kernel)
   ulonglong2* orec;                        // output records: 16-byte (key, iv) pairs, one dwordx4 access each
+  // histogram-free mode (hashed keys spread evenly): output partition j owns the fixed slot [j * slot, (j + 1) * slot) of
+  // orec and its cursor starts at j * slot; no histogram pass, no offset scan.  A partition that outgrows its slot raises
+  // *overflow (its surplus records land in a dump area behind the output) and the host repeats the batch with exact offsets.  0 = exact offsets.
+  uint64_t slot;
+  uint64_t dump;                           // first record of the dump area in orec (KH_PART_TILE records)
+  uint32_t* overflow;
 };
 
 // partition id of a hash: chunk id at the partitioning capacity, bit-reversed so that the
@@ -663,7 +669,13 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
       const uint32_t c = hist[b];
       loff[b] = run;
       run += c;
-      if (c) gres[k] = atomicAdd(&P.cursor[(uint64_t)d.seg * nb + b], (unsigned long long)c);
+      if (c) {
+        unsigned long long g = atomicAdd(&P.cursor[(uint64_t)d.seg * nb + b], (unsigned long long)c);
+        // histogram-free mode: a reservation that runs over the partition's slot is redirected, whole, to the dump area behind
+        // the output (one tile's worth of records) and the batch is flagged for a second try with exact offsets
+        if (P.slot && g + c > ((uint64_t)d.seg * nb + b + 1) * P.slot) { *P.overflow = 1u; g = P.dump + loff[b]; }
+        gres[k] = g;
+      }
     }
   }
   __syncthreads();
@@ -753,8 +765,39 @@ __global__ void k_seg_offsets(const uint64_t* __restrict__ part_off, uint32_t nb
   if (s <= nb1) { const uint64_t v = part_off[(uint64_t)s * nb2]; segoff[s] = v; if (s < nb1) cur1[s] = v; }
 }
 
-// tiles of KH_PART_TILE records that never straddle a segment (second partition pass)
-__global__ void k_make_tiles(const uint64_t* __restrict__ segoff, uint32_t nseg, KhTile* __restrict__ tiles, uint32_t* __restrict__ ntiles_out) {
+// Is the batch heavy in duplicates?  (Only then are the partitions of hashed keys uneven enough to outgrow the fixed slots of
+// the histogram-free partition.)  KH_SAMPLE_N keys at a regular stride go into an open-addressing set in global memory; a key met
+// again counts as a duplicate.  benchmark_hashtables' input (x5.5 multiplicity, 1.8e7 distinct of 1e8) gives ~120 hits, distinct
+// k-mers none; a few keys with 10^4 copies among 10^8 slip through -- the slot overflow flag catches those.
+#define KH_SAMPLE_N 65536u
+#define KH_SAMPLE_SET (1u << 18)
+__global__ void k_sample_dups(const char* __restrict__ kbase, uint32_t kstride, uint64_t n, unsigned long long* __restrict__ set /* zeroed */,
+                              uint32_t* __restrict__ dups) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= KH_SAMPLE_N) return;
+  const uint64_t pos = (uint64_t)i * (n / KH_SAMPLE_N);
+  const unsigned long long key = *reinterpret_cast<const uint64_t*>(kbase + pos * kstride) ^ 0x8000000000000001ull;     // (0 marks an empty entry)
+  const unsigned long long tag = key ? key : 1ull;
+  uint32_t slot = (uint32_t)kh_fmix64(tag) & (KH_SAMPLE_SET - 1);
+  for (;;) {
+    const unsigned long long cur = atomicCAS(&set[slot], 0ull, tag);
+    if (cur == 0ull) break;
+    if (cur == tag) { atomicAdd(dups, 1u); break; }
+    slot = (slot + 1) & (KH_SAMPLE_SET - 1);
+  }
+}
+
+// histogram-free partition: cursor[j] = j * slot (and, if asked, the same values as partition start offsets)
+__global__ void k_init_cursors(unsigned long long* __restrict__ cursor, uint64_t* __restrict__ starts, uint64_t n, uint64_t slot) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) cursor[i] = i * slot;
+  if (starts && i <= n) starts[i] = i * slot;
+}
+
+// tiles of KH_PART_TILE records that never straddle a segment (second partition pass).  slot != 0: segment s is the fixed
+// slot [s * slot, cursor[s]) that the first, histogram-free pass filled (clamped to the slot).
+__global__ void k_make_tiles(const uint64_t* __restrict__ segoff, uint32_t nseg, KhTile* __restrict__ tiles, uint32_t* __restrict__ ntiles_out,
+                             const unsigned long long* __restrict__ cursor = nullptr, uint64_t slot = 0) {
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t carry_s;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -763,7 +806,10 @@ __global__ void k_make_tiles(const uint64_t* __restrict__ segoff, uint32_t nseg,
   for (uint32_t base = 0; base < nseg; base += 1024) {
     uint32_t s = base + tid;
     uint64_t beg = 0, len = 0;
-    if (s < nseg) { beg = segoff[s]; len = segoff[s + 1] - beg; }
+    if (s < nseg) {
+      if (slot) { beg = (uint64_t)s * slot; len = cursor[s] - beg; if (len > slot) len = slot; }
+      else { beg = segoff[s]; len = segoff[s + 1] - beg; }
+    }
     uint32_t nt = (uint32_t)((len + KH_PART_TILE - 1) / KH_PART_TILE);
     uint32_t incl = nt;
     for (int off = 1; off < 64; off <<= 1) {
@@ -905,6 +951,8 @@ __device__ __forceinline__ uint32_t kh_dd_fold(unsigned long long* lk, unsigned 
 struct KhSrcSet {
   const ulonglong2* rec[KH_MAX_SRC];     // partitioned records of source s
   const uint64_t* off[KH_MAX_SRC];       // [nparts+1] partition offsets inside rec[s]
+  uint64_t slot[KH_MAX_SRC];             // != 0: histogram-free source: partition q = rec[s][q * slot, cur[s][q]) (clamped to the slot)
+  const unsigned long long* cur[KH_MAX_SRC];
   uint32_t n;                            // number of sources (>= 1)
   const uint64_t* merged_off;            // [nparts+1] sum over the sources of off[s][q]: where partition q's OUTPUT list starts
 };
@@ -922,6 +970,13 @@ __device__ __forceinline__ KhSrcView kh_src_setup(const KhSrcSet& S, uint32_t q,
   KhSrcView V;
   V.n = S.n;
   if (S.n == 1) {
+    if (S.slot[0]) {
+      const uint64_t b = (uint64_t)q * S.slot[0];
+      const uint64_t c = S.cur[0][q] - b;
+      V.one = S.rec[0] + b;
+      V.m = (uint32_t)(c < S.slot[0] ? c : S.slot[0]);
+      return V;
+    }
     const uint64_t b = S.off[0][q];
     V.one = S.rec[0] + b;
     V.m = (uint32_t)(S.off[0][q + 1] - b);

@@ -132,6 +132,7 @@ struct kh_table {
     KhSrcSet S;
     uint64_t* stage_k; uint32_t* stage_v;
   } ins;
+  uint32_t* part_overflow;      // device flag of the histogram-free partition feeding the operation in flight (or null)
   bool prof;
   std::vector<ProfRec> recs;
   std::vector<std::pair<std::string, std::pair<double, uint64_t> > > prof_acc;
@@ -358,6 +359,8 @@ kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(t->hpin, blk + sz_pub, 128, hipMemcpyDeviceToHost, t->stream));
+  t->hpin[30] = 0;
+  if (t->part_overflow) HIPCHK(hipMemcpyAsync(t->hpin + 30, t->part_overflow, 4, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   out->totals = totals; out->flags = F.flags;
   return KH_OK;
@@ -485,13 +488,60 @@ struct Partitioned {
   uint64_t* part_off;                           // [nparts+1]
   uint32_t PB, nparts;
   ulonglong2* spare;                            // the other record buffer (free for outputs)
+  uint64_t slot;                                // != 0: histogram-free layout: partition q = rec[q * slot, cursor[q])
+  const unsigned long long* cursor;
+  uint32_t* overflow;                           // device flag: a partition outgrew its slot (the batch must be redone with exact offsets)
 };
+// slot of a histogram-free partition with mean m records: m + 7 sigma (hashed keys: Poisson) + a little
+inline uint64_t slack_slot(double mean) { return (uint64_t)(mean + 7.0 * std::sqrt(mean) + 16.0); }
+const bool g_disable_slack = getenv("KH_DISABLE_SLACK_PARTITION") != nullptr;      // test hook: exact offsets always
+// records the two buffers of partition_batch must hold
+inline uint64_t part_buffer_records(uint64_t n, uint32_t PB, bool allow_slack) {
+  if (!allow_slack || g_disable_slack || PB <= 11 || n < (uint64_t(256) << PB)) return n;
+  return (slack_slot((double)n / (double)(uint64_t(1) << PB)) << PB) + KH_PART_TILE;        // slots + the dump area of the scatter
+}
 
 // Partitions n input pairs into `fin` (n records); `tmp` (n records) is scratch for the first of two passes.  idx_base =
 // stream position of the first pair (pairs fed before it in a streamed insert).  Asynchronous on the table's stream.
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
-                          uint32_t vconst, uint64_t n, uint64_t idx_base, uint32_t PB, ulonglong2* tmp, ulonglong2* fin, Partitioned& out) {
+                          uint32_t vconst, uint64_t n, uint64_t idx_base, uint32_t PB, ulonglong2* tmp, ulonglong2* fin, Partitioned& out,
+                          bool allow_slack = false) {
   const uint32_t nparts = 1u << PB;
+  out.slot = 0; out.cursor = nullptr; out.overflow = nullptr;
+  if (part_buffer_records(n, PB, allow_slack) != n) {
+    // ---- histogram-free two-pass partition: hashed keys fill the 2^PB partitions evenly, so every partition
+    // gets a fixed slot of mean + 7 sigma records and the passes reserve space with their cursors alone: no histogram sweep
+    // over the keys (0.33 ms per 1e8), no offset scan.  Level-1 buckets are the unions of their partitions' slots.
+    const uint32_t B1 = (PB + 1) / 2, B2 = PB - B1, nb1 = 1u << B1, nb2 = 1u << B2;
+    const uint64_t slot = slack_slot((double)n / (double)nparts), slot1 = slot * nb2;
+    unsigned long long *cur1, *cur2; uint64_t* starts; uint32_t* ovf; KhTile* tiles; uint32_t* ntiles_dev;
+    const uint32_t max_tiles = (uint32_t)(n / KH_PART_TILE) + nb1 + 1;
+    TAKE(cur1, unsigned long long, nb1); TAKE(cur2, unsigned long long, nparts); TAKE(starts, uint64_t, (size_t)nparts + 1); TAKE(ovf, uint32_t, 1);
+    TAKE(tiles, KhTile, max_tiles); TAKE(ntiles_dev, uint32_t, 1);
+    HIPCHK(hipMemsetAsync(ovf, 0, 4, t->stream));
+    hipLaunchKernelGGL(k_init_cursors, dim3((nb1 + 255) / 256), dim3(256), 0, t->stream, cur1, (uint64_t*)nullptr, (uint64_t)nb1, slot1);
+    hipLaunchKernelGGL(k_init_cursors, dim3((nparts + 256) / 256), dim3(256), 0, t->stream, cur2, starts, (uint64_t)nparts, slot);
+    KhPartParams P;
+    memset(&P, 0, sizeof(P));
+    P.idx_base = idx_base;
+    P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.n = n;
+    P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
+    P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.cursor = cur1; P.orec = tmp; P.slot = slot1; P.overflow = ovf; P.dump = slot * nparts;
+    { Launch L(t, "k_part_scatter");
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
+    { Launch L(t, "k_make_tiles");
+      hipLaunchKernelGGL(k_make_tiles, dim3(1), dim3(1024), 0, t->stream, (const uint64_t*)nullptr, nb1, tiles, ntiles_dev, (const unsigned long long*)cur1, slot1); }
+    KhPartParams Q = P;
+    Q.kbase = nullptr; Q.kstride = 0; Q.vbase = nullptr; Q.vstride = 0; Q.rec_in = tmp;
+    Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
+    Q.shift = 0; Q.nb = nb2; Q.cursor = cur2; Q.orec = fin; Q.slot = slot;
+    { Launch L(t, "k_part_scatter");
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
+    HIPCHK(hipGetLastError());
+    out.rec = fin; out.part_off = starts; out.PB = PB; out.nparts = nparts; out.spare = tmp;
+    out.slot = slot; out.cursor = cur2; out.overflow = ovf;
+    return KH_OK;
+  }
   ulonglong2* ar = nullptr; ulonglong2* br = fin;
   const uint32_t B1 = PB <= 11 ? PB : (PB + 1) / 2, B2 = PB - B1;
   const uint32_t nb1 = 1u << B1, nb2 = 1u << B2;
@@ -588,8 +638,9 @@ enum { INS_FIRST = 0, INS_UPDATE = 1, INS_PLUS = 2 };
 bool g_disable_fused = getenv("KH_DISABLE_FUSED_BUILD") != nullptr;   // test hook: force the general path
 
 // second half of an insert: the n pairs have been partitioned (one source per feed); de-dup, capacity decision, build
+const kh_status KH_RETRY_EXACT = static_cast<kh_status>(100);      // internal: a histogram-free partition overflowed a slot
 kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64_t cap_u, int mode, uint64_t forced_cap,
-                        ulonglong2* spare, uint64_t* n_new_out);
+                        ulonglong2* spare, uint64_t* n_new_out, uint64_t list_cap = 0);
 
 // core of insert/update for one batch of device-resident input (n < 2^32 - 16)
 kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
@@ -599,20 +650,45 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   const uint64_t cap_u = forced_cap ? forced_cap : capacity_after(t, t->cur.cap, t->lsize, n, n, n - 1);
   const uint32_t PB = cap_u > KH_L ? log2u(cap_u >> KH_LB) : 0u;
   if (PB > 22) return fail(t, KH_ERR_UNSUPPORTED, "batch would need more than 2^22 partitions");
-  ulonglong2 *tmp, *fin;
-  TAKE(tmp, ulonglong2, n); TAKE(fin, ulonglong2, n);
-  Partitioned R;
-  kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R);
-  if (st != KH_OK) return st;
-  KhSrcSet S;
-  memset(&S, 0, sizeof(S));
-  S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off;
-  return insert_finish(t, S, n, PB, cap_u, mode, forced_cap, tmp, n_new_out);
+  const size_t keep_blk = t->blk, keep_off = t->off;
+  int first_attempt = 0;
+  if (part_buffer_records(n, PB, true) != n) {
+    // histogram-free partition only for batches a sample finds (nearly) free of duplicates
+    unsigned long long* sset; uint32_t* dups;
+    TAKE(sset, unsigned long long, KH_SAMPLE_SET); TAKE(dups, uint32_t, 1);
+    HIPCHK(hipMemsetAsync(sset, 0, sizeof(unsigned long long) * KH_SAMPLE_SET, t->stream));
+    HIPCHK(hipMemsetAsync(dups, 0, 4, t->stream));
+    { Launch L(t, "k_sample_dups");
+      hipLaunchKernelGGL(k_sample_dups, dim3(KH_SAMPLE_N / 256), dim3(256), 0, t->stream, kbase, kstride, n, sset, dups); }
+    HIPCHK(hipMemcpyAsync(t->hpin + 31, dups, 4, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if ((uint32_t)t->hpin[31] >= 8u) first_attempt = 1;
+    t->blk = keep_blk; t->off = keep_off;
+  } else first_attempt = 1;
+  for (int attempt = first_attempt; attempt < 2; ++attempt) {
+    const bool slack = attempt == 0;          // histogram-free first; exact offsets if a partition outgrew its slot (skewed keys)
+    const uint64_t m = part_buffer_records(n, PB, slack);
+    if (!slack && attempt == 1) { t->blk = keep_blk; t->off = keep_off; }
+    ulonglong2 *tmp, *fin;
+    TAKE(tmp, ulonglong2, m); TAKE(fin, ulonglong2, m);
+    Partitioned R;
+    kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R, slack);
+    if (st != KH_OK) return st;
+    KhSrcSet S;
+    memset(&S, 0, sizeof(S));
+    S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off; S.slot[0] = R.slot; S.cur[0] = R.cursor;
+    t->part_overflow = R.overflow;
+    st = insert_finish(t, S, n, PB, cap_u, mode, forced_cap, tmp, n_new_out, m);
+    t->part_overflow = nullptr;
+    if (st != KH_RETRY_EXACT) return st;
+  }
+  return fail(t, KH_ERR_HIP, "internal: exact partition reported a slot overflow");
 }
 
 kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64_t cap_u, int mode, uint64_t forced_cap,
-                        ulonglong2* spare, uint64_t* n_new_out) {
+                        ulonglong2* spare, uint64_t* n_new_out, uint64_t list_cap) {
   *n_new_out = 0;
+  if (list_cap < n) list_cap = n;       // entries the per-partition output lists span (slots of a histogram-free partition: > n)
   kh_status st = KH_OK;
   const uint32_t nparts = 1u << PB;
   struct { uint32_t nparts; } R; R.nparts = nparts;
@@ -633,6 +709,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
     FusedRun run;
     { kh_status fs = launch_fused(t, 0, F, nw, PB, "k_build_fused", &run); if (fs != KH_OK) return fs; }
+    if (t->part_overflow && (uint32_t)t->hpin[30]) { retire_slots(t, nw); return KH_RETRY_EXACT; }
     unsigned long long* totals = run.totals;
     const uint64_t fd = t->hpin[0];
     const uint64_t flast = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
@@ -689,6 +766,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.R.Old = t->cur; F.R.PB = PB;
     FusedRun run;
     { kh_status fs = launch_fused(t, 2, F, nw, PB, "k_insert_fused", &run); if (fs != KH_OK) return fs; }
+    if (t->part_overflow && (uint32_t)t->hpin[30]) { retire_slots(t, nw); return KH_RETRY_EXACT; }
     const uint64_t total = t->hpin[0];
     const uint64_t fd = total >= t->lsize ? total - t->lsize : 0;
     const uint64_t flast = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
@@ -720,7 +798,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   KhDedupParams D;
   D.src = S;
   // outputs go into the scratch record buffer (16 B per input record): keys in its first half, values behind them
-  D.nk = reinterpret_cast<uint64_t*>(spare); D.nv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(spare) + n * 8);
+  D.nk = reinterpret_cast<uint64_t*>(spare); D.nv = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(spare) + list_cap * 8);
   D.cnt_new = cnt_new; D.max_idx_plus1 = scal;
   // speculate that the capacity decided below equals cap_u (true whenever the batch holds few duplicates): then the
   // de-dup kernel already produces the chunk counts and k_chunk_count is skipped
@@ -739,7 +817,10 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   HIPCHK(hipMemcpyAsync(t->hpin, noff + R.nparts, 8, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipMemcpyAsync(t->hpin + 1, scal, 8, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipMemcpyAsync(t->hpin + 2, flags, sizeof(uint32_t) * KH_NFLAGS, hipMemcpyDeviceToHost, t->stream));
+  t->hpin[30] = 0;
+  if (t->part_overflow) HIPCHK(hipMemcpyAsync(t->hpin + 30, t->part_overflow, 4, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
+  if (t->part_overflow && (uint32_t)t->hpin[30]) return KH_RETRY_EXACT;
   const uint64_t dnew = t->hpin[0];
   const uint64_t last_first = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
   if (reinterpret_cast<const uint32_t*>(t->hpin + 2)[KH_FLAG_INTERNAL])
@@ -946,7 +1027,7 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
   { const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n ? n : 1, n, n ? n - 1 : 0);
     const bool ip = inplace_ok(t, n) && t->lsize + n <= t->max_load;      // in place: no re-layout workspace, bins instead
     kh_status ps = ip ? arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_inplace(t, n))
-                      : arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
+                      : arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 58 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
     if (ps != KH_OK) return ps; }
   const char* kb = static_cast<const char*>(keys);
   const char* vb = static_cast<const char*>(vals);
@@ -1207,7 +1288,7 @@ kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t v
   t->kind = (int)kind; t->hash = (int)hash; t->device = device; t->seed = KhSeed{seed, 0u}; t->stream = nullptr;
   t->min_lf = min_lf; t->max_lf = max_lf; t->lsize = 0;
   t->cur = kNoSlots; t->spare = t->cur;
-  t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false;
+  t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false; t->part_overflow = nullptr;
   memset(&t->ins, 0, sizeof(t->ins));
   const uint64_t cap = next_pow2(capacity);
   if (alloc_slots(t, cap, t->cur) != KH_OK) { delete t; return KH_ERR_NOMEM; }

@@ -996,3 +996,31 @@ def test_fused_build_look_back_time_out_falls_back_to_the_general_path():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KH_DEBUG_POLL_LIMIT="0"), capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "time-out path ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_histogram_free_partition_and_its_fall_backs(oracle):
+    """a large batch of (nearly) distinct hashed keys is partitioned without a histogram pass (fixed slots of mean + 7
+    sigma per partition).  A sample decides: duplicate-heavy batches take exact offsets from the start; duplicates the sample misses
+    (one key repeated 30000 times among 4e6 distinct ones) overflow a slot and the batch is redone with exact offsets."""
+    n = 4_000_000                                   # capacity 2^23: 4096 partitions (two partition passes) of ~977 records
+    keys = W.distinct_u64(n, seed=123); vals = np.arange(n, dtype=np.uint32)
+    for variant in ("distinct", "duplicate_heavy", "hidden_skew"):
+        if variant == "duplicate_heavy":
+            k, v = W.w1_benchmark_hashtables(n, seed=9)
+        elif variant == "hidden_skew":
+            k = keys.copy(); k[(n // 65536) * np.arange(30_000) + 1] = keys[7]; v = vals      # between the sample's positions (stride n // 65536)
+        else:
+            k, v = keys, vals
+        g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8); o = oracle.OracleTable(0, 128, 0.35, 0.8)
+        g.profile_enable(True)
+        assert g.insert(dev(k), dev(v)) == o.insert(k, v)
+        p = g.profile()
+        assert "k_sample_dups" in p
+        if variant == "distinct":
+            assert "k_part_hist" not in p and p["k_part_scatter"][0] == 2, p
+        elif variant == "duplicate_heavy":
+            assert "k_part_hist" in p and p["k_part_scatter"][0] == 2, p
+        else:
+            assert "k_part_hist" in p and p["k_part_scatter"][0] == 4, p       # histogram-free attempt, then exact
+        check_state(g, o, 0)
+        g.close()
