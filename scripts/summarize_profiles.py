@@ -38,10 +38,15 @@ for k, e in res.items():
     e["read_correction"] = "x2 (coalesced streaming read, gfx950)" if streaming else "raw (random access, uncalibrated)"
     e["write_bytes_per_launch"] = w
     e["hbm_bytes_per_launch"] = e["read_bytes_per_launch"] + w
+# HBM bytes of one insert batch = sum over the kernels of the insert path (everything but the query kernels), per bench step
+# (the PMC passes run bench.py --steps 1 --warmup 0: launches = launches per batch)
+INSERT_PATH = ("k_part_", "k_build_fused", "k_fused_", "k_make_tiles", "k_scan", "k_init_cursors", "k_sample_dups", "k_seg_offsets", "k_dedup", "k_chunk_")
+ins = sum(e["hbm_bytes_per_launch"] * max(e.get("FETCH_SIZE_launches", 0), e.get("WRITE_SIZE_launches", 0)) for k, e in res.items() if k.startswith(INSERT_PATH))
+res["_insert_path"] = {"hbm_bytes_per_batch": ins, "kernels": sorted(k for k in res if k.startswith(INSERT_PATH))}
 json.dump(res, open("profiles/%s_pmc_hbm_traffic.json" % tag, "w"), indent=1, sort_keys=True)
 with open("profiles/%s_pmc_hbm_traffic.csv" % tag, "w") as f:
     f.write("kernel,launches,FETCH_KB_raw_per_launch,WRITE_KB_raw_per_launch,read_bytes_corrected,write_bytes,hbm_bytes_per_launch\n")
-    for k, e in sorted(res.items(), key=lambda x: -x[1]["hbm_bytes_per_launch"]):
+    for k, e in sorted(((k, e) for k, e in res.items() if not k.startswith("_")), key=lambda x: -x[1]["hbm_bytes_per_launch"]):
         f.write("%s,%d,%.1f,%.1f,%.0f,%.0f,%.0f\n" % (k, e.get("FETCH_SIZE_launches", 0), e.get("FETCH_SIZE_KB_per_launch_raw", 0),
                                                    e.get("WRITE_SIZE_KB_per_launch_raw", 0), e["read_bytes_per_launch"],
                                                    e["write_bytes_per_launch"], e["hbm_bytes_per_launch"]))
