@@ -765,6 +765,37 @@ __global__ void k_seg_offsets(const uint64_t* __restrict__ part_off, uint32_t nb
   if (s <= nb1) { const uint64_t v = part_off[(uint64_t)s * nb2]; segoff[s] = v; if (s < nb1) cur1[s] = v; }
 }
 
+// Small batches (<= 32768 pairs, <= 32 partitions): the whole partition in ONE launch.  Workgroup q sweeps the input (it stays in
+// L2) and keeps the records of partition q in its own slot of n records (any skew fits); the cursor / start arrays are what the
+// histogram-free layout uses (partition q = orec[q * n, cursor[q])).  Replaces histogram + scan + scatter (and their memsets) where
+// the launches, not the bytes, are the cost: the in-place path for batches of middle size.
+__device__ __forceinline__ uint32_t kh_wave_append(bool want, uint32_t* counter);      // (defined with the de-dup helpers below)
+template <int HASH>
+__global__ __launch_bounds__(512) void k_part_direct(const char* __restrict__ kbase, uint32_t kstride, const char* __restrict__ vbase, uint32_t vstride,
+                                                     uint32_t vconst, uint64_t n, KhSeed seed, uint32_t PB, ulonglong2* __restrict__ orec,
+                                                     unsigned long long* __restrict__ cursor, uint64_t* __restrict__ starts) {
+  __shared__ uint32_t cnt;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  for (uint64_t i0 = 0; i0 < n; i0 += 512) {
+    const uint64_t i = i0 + tid;
+    bool take = false;
+    uint64_t key = 0;
+    if (i < n) {
+      key = *reinterpret_cast<const uint64_t*>(kbase + i * kstride);
+      take = kh_part_q(kh_hash64<HASH>(key, seed), PB) == q;
+    }
+    const uint32_t pos = kh_wave_append(take, &cnt);
+    if (take) {
+      const unsigned long long iv = ((unsigned long long)i << 32) | (vbase ? *reinterpret_cast<const uint32_t*>(vbase + i * vstride) : vconst);
+      orec[(uint64_t)q * n + pos] = make_ulonglong2(key, iv);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { cursor[q] = (uint64_t)q * n + cnt; starts[q] = (uint64_t)q * n; if (q == 0) starts[gridDim.x] = (uint64_t)gridDim.x * n; }
+}
+
 // Is the batch heavy in duplicates?  (Only then are the partitions of hashed keys uneven enough to outgrow the fixed slots of
 // the histogram-free partition.)  KH_SAMPLE_N keys at a regular stride go into an open-addressing set in global memory; a key met
 // again counts as a duplicate.  benchmark_hashtables' input (x5.5 multiplicity, 1.8e7 distinct of 1e8) gives ~120 hits, distinct
@@ -2450,8 +2481,9 @@ __global__ void k_ip_bin(KhInplaceParams P) {
 }
 
 // one LANE per region
+#define KH_IP_THREADS 1024
 template <int HASH, int OP>
-__global__ void k_ip_apply(KhInplaceParams P) {
+__global__ __launch_bounds__(KH_IP_THREADS) void k_ip_apply(KhInplaceParams P) {
   const uint64_t mask = P.T.cap - 1;
   const uint32_t regions = (uint32_t)(P.T.cap >> KH_IP_LB);
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2469,8 +2501,17 @@ __global__ void k_ip_apply(KhInplaceParams P) {
       else if (st == KH_IP_TOO_FAR) atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u);
     }
   }
+  // one atomic per WORKGROUP of 1024 lanes: a same-address atomic per wave (4096 of them for 2^18 regions) serialises in the L2 at
+  // ~15 ns each -- 60 of the 77 us this kernel took for 10^4 keys
+  __shared__ uint32_t s_done[16];
   for (int off = 32; off > 0; off >>= 1) done += __shfl_down(done, off, 64);
-  if ((threadIdx.x & 63) == 0 && done) atomicAdd(P.n_done, (unsigned long long)done);
+  if ((threadIdx.x & 63) == 0) s_done[threadIdx.x >> 6] = done;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) tot += s_done[w];
+    if (tot) atomicAdd(P.n_done, (unsigned long long)tot);
+  }
 }
 
 // what two binned passes could not place: one lane, unbounded

@@ -920,7 +920,7 @@ inline bool inplace_ok(const kh_table* t, uint64_t n) {
   return !g_disable_inplace && t->kind == KHK_RH && n > KH_SMALL_N && t->lsize > 0 && t->cur.cap >= 16 * (uint64_t)KH_IP_L &&
          n <= (t->cur.cap >> KH_IP_LB) && t->lsize + n <= threshold(t->cur.cap, 0.85f);
 }
-inline size_t ws_inplace(const kh_table* t, uint64_t n) { return n * 32 + (t->cur.cap >> KH_IP_LB) * (size_t)(KH_IP_CAP * 16 + 8) + (size_t(1) << 20); }
+inline size_t ws_inplace(const kh_table* t, uint64_t n) { return n * 32 + (n <= 32768 ? n * 32 * 32 : 0) + (t->cur.cap >> KH_IP_LB) * (size_t)(KH_IP_CAP * 16 + 8) + (size_t(1) << 20); }
 // result block of the in-place passes (device, zero at launch; copied to t->hpin in one piece)
 struct IpResult { unsigned long long defer1, defer2, done, n_in; uint32_t flags[KH_NFLAGS]; };
 // the three passes over the input list `src` describes (fields in_* / part_* / n of P0): regions, regions shifted by half, one lane
@@ -938,21 +938,21 @@ kh_status inplace_passes(kh_table* t, const KhInplaceParams& src, uint64_t n_max
   uint32_t* cnt = reinterpret_cast<uint32_t*>(z + sizeof(IpResult));
   KhInplaceParams P = src;
   P.T = t->cur; P.seed = t->seed; P.bins = bins; P.n_done = &res->done; P.n_in = &res->n_in; P.flags = res->flags;
-  const uint32_t apply_grid = (regions + 63) / 64;
+  const uint32_t apply_grid = (regions + KH_IP_THREADS - 1) / KH_IP_THREADS;
   // pass 1: regions [r L, (r+1) L)
   P.ofs = 0; P.cnt = cnt; P.defer = defer1; P.n_defer = &res->defer1;
   { Launch L(t, "k_ip_bin");
     const uint32_t grid = P.part_off ? std::min<uint32_t>(P.nparts, 4096u) : grid_for(n_max, 256);
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_bin<HASH>), dim3(grid), dim3(256), 0, t->stream, P)); }
   { Launch L(t, "k_ip_apply");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_apply<HASH, OP>), dim3(apply_grid), dim3(64), 0, t->stream, P)); }
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_apply<HASH, OP>), dim3(apply_grid), dim3(KH_IP_THREADS), 0, t->stream, P)); }
   // pass 2: what crossed a boundary, regions shifted by half a region
   P.ofs = KH_IP_L / 2; P.in_k = nullptr; P.in_v = nullptr; P.part_off = nullptr; P.in_rec = defer1; P.n = 0; P.n_dev = &res->defer1;
   P.cnt = cnt + regions; P.defer = defer2; P.n_defer = &res->defer2;
   { Launch L(t, "k_ip_bin2");
     KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_bin<HASH>), dim3(grid_for(std::max<uint64_t>(n_max / 8, 256), 256)), dim3(256), 0, t->stream, P)); }
   { Launch L(t, "k_ip_apply2");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_apply<HASH, OP>), dim3(apply_grid), dim3(64), 0, t->stream, P)); }
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_ip_apply<HASH, OP>), dim3(apply_grid), dim3(KH_IP_THREADS), 0, t->stream, P)); }
   // pass 3: the rest, one lane
   P.in_rec = defer2; P.n_dev = &res->defer2;
   { Launch L(t, "k_ip_serial");
@@ -969,19 +969,34 @@ kh_status insert_inplace(kh_table* t, const char* kb, uint32_t kstride, const ch
   // batch's distinct NEW keys, one list per partition, which the binning kernel reads where they lie
   uint32_t PB = 0;
   while (PB < 11 && (n >> PB) > 1024) ++PB;
-  ulonglong2 *tmp, *fin;
-  TAKE(tmp, ulonglong2, n); TAKE(fin, ulonglong2, n);
   Partitioned R;
-  kh_status st = partition_batch(t, kb, kstride, vb, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R);
-  if (st != KH_OK) return st;
+  kh_status st = KH_OK;
+  uint64_t list_cap = n;                       // entries the per-partition output lists of k_dedup span
+  if (n <= 32768) {
+    // one launch: workgroup q keeps partition q in its own slot of n records (k_part_direct)
+    const uint32_t nparts = 1u << PB;
+    list_cap = (uint64_t)nparts * n;
+    ulonglong2 *rec, *spare; unsigned long long* cur; uint64_t* starts;
+    TAKE(rec, ulonglong2, list_cap); TAKE(spare, ulonglong2, list_cap); TAKE(cur, unsigned long long, nparts); TAKE(starts, uint64_t, (size_t)nparts + 1);
+    { Launch L(t, "k_part_direct");
+      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_direct<HASH>), dim3(nparts), dim3(512), 0, t->stream, kb, kstride, vb, vstride,
+                                                 mode == INS_PLUS ? 1u : 0u, n, t->seed, PB, rec, cur, starts)); }
+    HIPCHK(hipGetLastError());
+    R.rec = rec; R.part_off = starts; R.PB = PB; R.nparts = nparts; R.spare = spare; R.slot = n; R.cursor = cur; R.overflow = nullptr;
+  } else {
+    ulonglong2 *tmp, *fin;
+    TAKE(tmp, ulonglong2, n); TAKE(fin, ulonglong2, n);
+    st = partition_batch(t, kb, kstride, vb, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R);
+    if (st != KH_OK) return st;
+  }
   KhSrcSet S;
   memset(&S, 0, sizeof(S));
-  S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off;
+  S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off; S.slot[0] = R.slot; S.cur[0] = R.cursor;
   uint32_t* cnt_new;
   TAKE(cnt_new, uint32_t, R.nparts);
   KhInplaceParams src;
   memset(&src, 0, sizeof(src));
-  src.in_k = reinterpret_cast<uint64_t*>(R.spare); src.in_v = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(R.spare) + n * 8);
+  src.in_k = reinterpret_cast<uint64_t*>(R.spare); src.in_v = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(R.spare) + list_cap * 8);
   src.part_off = R.part_off; src.part_cnt = cnt_new; src.nparts = R.nparts;
   KhDedupParams D;
   memset(&D, 0, sizeof(D));
