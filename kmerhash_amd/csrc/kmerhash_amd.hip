@@ -1252,7 +1252,7 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
   TAKE(cnt, unsigned long long, 1);
   HIPCHK(hipMemsetAsync(cnt, 0, 8, t->stream));
   { Launch L(t, "k_erase_mark");
-    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_erase_mark<KIND, HASH>), dim3(grid_for(n, KH_Q_THREADS)), dim3(KH_Q_THREADS), 0, t->stream, t->cur, q, n, t->seed, cnt)); }
+    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_erase_mark<KIND, HASH>), dim3(grid_for(n, KH_Q_THREADS * KH_Q_ITEMS, 2048)), dim3(KH_Q_THREADS), 0, t->stream, t->cur, q, n, t->seed, cnt)); }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(t->hpin, cnt, 8, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
