@@ -41,47 +41,16 @@ extern "C" int madvise(void* addr, size_t len, int advice) noexcept;
 #endif
 
 #include "../kmerhash_amd.h"
+#include "kh_hash.h"
 
 namespace kmerhash_amd {
 namespace detail {
 
-// scalar host evaluation of the same hashes the kernels use (kmerhash_amd/csrc/kh_hash.h restated for the host
-// shim so that this header only depends on the C-ABI header)
-inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
-inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
-inline uint64_t rotr64(uint64_t x, int r) { return (x >> r) | (x << (64 - r)); }
-inline uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
-inline uint64_t fmix64(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k; }
-inline uint64_t murmur3_x86_128_lo64(uint64_t key, uint32_t seed) {
-  const uint32_t c1 = 0x239b961bu, c2 = 0xab0e9789u, c3 = 0x38b34ae5u;
-  uint32_t h1 = seed, h2 = seed, h3 = seed, h4 = seed, k1 = uint32_t(key), k2 = uint32_t(key >> 32);
-  k2 *= c2; k2 = rotl32(k2, 16); k2 *= c3; h2 ^= k2;
-  k1 *= c1; k1 = rotl32(k1, 15); k1 *= c2; h1 ^= k1;
-  h1 ^= 8u; h2 ^= 8u; h3 ^= 8u; h4 ^= 8u;
-  h1 += h2; h1 += h3; h1 += h4; h2 += h1; h3 += h1; h4 += h1;
-  h1 = fmix32(h1); h2 = fmix32(h2); h3 = fmix32(h3); h4 = fmix32(h4);
-  h1 += h2; h1 += h3; h1 += h4; h2 += h1;
-  return uint64_t(h1) | (uint64_t(h2) << 32);
-}
-inline uint64_t murmur3_x64_128_h0(uint64_t key, uint32_t seed) {
-  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
-  uint64_t h1 = seed, h2 = seed, k1 = key;
-  k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-  h1 ^= 8u; h2 ^= 8u; h1 += h2; h2 += h1;
-  h1 = fmix64(h1); h2 = fmix64(h2);
-  return h1 + h2;
-}
-inline uint64_t farm_len16(uint64_t u, uint64_t v, uint64_t mul) {
-  uint64_t a = (u ^ v) * mul; a ^= (a >> 47);
-  uint64_t b = (v ^ a) * mul; b ^= (b >> 47);
-  return b * mul;
-}
-inline uint64_t farm64_seed(uint64_t key, uint64_t seed) {
-  const uint64_t k2 = 0x9ae16a3b2f90404fULL, mul = k2 + 16;
-  uint64_t a = key + k2, b = key;
-  uint64_t c = rotr64(b, 37) * mul + a, d = (rotr64(a, 25) + b) * mul;
-  return farm_len16(farm_len16(c, d, mul) - k2, seed, 0x9ddfea08eb382d69ULL);
-}
+// scalar host evaluation of the hashes: the SAME inline functions the kernels compile (kh_hash.h is host + device code), so the
+// functors' single-key operator() and the device agree by construction
+inline uint64_t murmur3_x86_128_lo64(uint64_t key, uint32_t seed) { return ::kh_murmur3_x86_128_lo64(key, seed); }
+inline uint64_t murmur3_x64_128_h0(uint64_t key, uint32_t seed) { return ::kh_murmur3_x64_128_h0(key, seed); }
+inline uint64_t farm64_seed(uint64_t key, uint64_t seed) { return ::kh_farm64_seed(key, seed); }
 // Result vectors of 10^7..10^8 elements are fresh mmap regions: touched 4 KB at a time their first-touch page faults cost
 // more than the whole device call (160 MB of find results: 27 ms, against 5.5 ms for H2D + kernels + D2H).  Asking for
 // transparent huge pages before the first touch brings that to 8 ms.  No-op where madvise/THP is not available.
@@ -195,7 +164,7 @@ namespace detail {
 // k of a k-mer key type (Key::size, as kmerind's Kmer and dna_kmer expose it); 0 = not a k-mer type
 template <typename Key, typename = void> struct kmer_size { static constexpr unsigned value = 0; };
 template <typename Key> struct kmer_size<Key, typename std::enable_if<(Key::size > 0)>::type> { static constexpr unsigned value = Key::size; };
-inline uint64_t revcomp_bits(uint64_t x, unsigned k) { uint64_t r = 0; for (unsigned i = 0; i < k; ++i) { r = (r << 2) | (3u - (x & 3u)); x >>= 2; } return r; }
+inline uint64_t revcomp_bits(uint64_t x, unsigned k) { return ::kh_revcomp(x, k); }
 }  // namespace detail
 }  // namespace kmerhash_amd
 #ifndef KMERHASH_AMD_NO_BLISS_STANDINS

@@ -1,4 +1,5 @@
-// kh_hash.h -- 64-bit hashes of one packed 64-bit k-mer, per lane (host + device).
+// kh_hash.h -- 64-bit hashes of one packed 64-bit k-mer, per lane (host + device).  ONE definition for the kernels
+// (kmerhash_amd/csrc/kh_kernels.h) and for the host-side functors of the C++ shim (hashmap.hpp); plain C++11.
 //
 // murmur3_x86_128 is the hash fsc::hash::murmur3avx64 computes 8 keys at a time with AVX2
 // (reference murmurhash3_64_avx.hpp:1083-1169, constants :1511-1521).  The AVX2 code splits every

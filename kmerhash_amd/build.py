@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "kmerhash_amd.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "kh_kernels.h"), os.path.join(HERE, "csrc", "kh_hash.h"),
+DEPS = [SRC, os.path.join(HERE, "csrc", "kh_kernels.h"), os.path.join(HERE, "..", "include", "kmerhash_amd", "kh_hash.h"),
         os.path.join(HERE, "..", "include", "kmerhash_amd.h")]
 LIB = os.path.join(HERE, "libkmerhash_amd.so")
 RES = os.path.join(HERE, "kernel_resources.json")      # per-kernel registers / LDS / occupancy reported by the compiler

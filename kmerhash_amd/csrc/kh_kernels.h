@@ -17,7 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "kh_hash.h"
+#include "../../include/kmerhash_amd/kh_hash.h"
 
 #define KH_LB 11                 // log2(chunk slots)
 #define KH_L (1u << KH_LB)       // chunk slots (home buckets per workgroup)
