@@ -1528,6 +1528,8 @@ struct KhFusedParams {
                                                          //     read consistently), [1] abort
   uint32_t* flags;
   long long poll_limit;                                  // cycles the look-back may wait for its predecessor (~4 ms; a test hook shortens it)
+  int nodup;                                             // SRC == 0: a sample of the batch found no duplicate -- skip the LDS hash-set fold and
+                                                         //   CHECK instead that no home bucket received two equal keys (any duplicate: general path)
   KhRebuildParams R;                                     // SRC == 1 only: source table, erase mask, new distinct elements
 };
 
@@ -1686,7 +1688,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       return;
     }
     // ---- de-dup (as k_dedup, single round)
-    for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+    const bool nodup = P.nodup && c != 0;            // (chunk 0 is parked, not placed here: it keeps the fold)
+    if (!nodup) for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
     {   // all (<= 4) records of a lane are requested before the first one is stored: one HBM round trip, not four
       ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
 #pragma unroll
@@ -1703,7 +1706,11 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     if (V.n > 1) __syncthreads();       // the source table (in simg[]) has been read by every lane
     for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
     __syncthreads();
-    rep_mask = kh_dd_fold(lk, liv, set, m, P.mode, P.seed.xk);
+    if (nodup) {                        // every record stands for itself; equal keys are looked for after the placement
+      rep_mask = 0;
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) if (it * KH_CHUNK_THREADS + tid < m) rep_mask |= 1u << it;
+    } else rep_mask = kh_dd_fold(lk, liv, set, m, P.mode, P.seed.xk);
     __syncthreads();
   } else if (SRC == 2) {
     // ---- insert into a non-empty table: the chunk's current elements + the batch's records of this chunk, folded together
@@ -1872,6 +1879,29 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     }
   }
   __syncthreads();
+  if (SRC == 0 && P.nodup && c != 0) {
+    // equal keys share their home bucket, hence sit in one group of consecutive slots [start[b], start[b] + cnt[b]): every
+    // element compares itself with the elements of its group behind it (groups hold ~1 element, rarely more than 4)
+    bool dup = false;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      if ((rep_mask >> it) & 1u) {
+        const uint32_t x = it * KH_CHUNK_THREADS + tid, b = hb[it];
+        const uint32_t g0 = start[b], g1 = g0 + cnt[b];
+        if (g1 > KH_L + KH_FSPILL) dup = true;                       // part of the group went past the image: cannot be checked here
+        else {
+          const unsigned long long key = lk[x];
+          bool after = false;
+          for (uint32_t sidx = g0; sidx < g1; ++sidx) {
+            const uint32_t xo = simg[sidx] & 0x7FFu;
+            if (xo == x) after = true;
+            else if (after && kh_keq(lk[xo], key, P.seed.xk)) dup = true;
+          }
+        }
+      }
+    }
+    if (__any(dup) && (tid & 63) == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+  }
   long long pend = s_pend;
   if (pend < (long long)KH_L) pend = KH_L;
   const uint32_t lo = (uint32_t)xr;

@@ -133,6 +133,7 @@ struct kh_table {
     uint64_t* stage_k; uint32_t* stage_v;
   } ins;
   uint32_t* part_overflow;      // device flag of the histogram-free partition feeding the operation in flight (or null)
+  bool batch_nodup;             // a sample of the batch in flight found no duplicate key (k_sample_dups)
   bool prof;
   std::vector<ProfRec> recs;
   std::vector<std::pair<std::string, std::pair<double, uint64_t> > > prof_acc;
@@ -663,6 +664,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     HIPCHK(hipMemcpyAsync(t->hpin + 31, dups, 4, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     if ((uint32_t)t->hpin[31] >= 8u) first_attempt = 1;
+    t->batch_nodup = (uint32_t)t->hpin[31] == 0u;
     t->blk = keep_blk; t->off = keep_off;
   } else first_attempt = 1;
   for (int attempt = first_attempt; attempt < 2; ++attempt) {
@@ -679,7 +681,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off; S.slot[0] = R.slot; S.cur[0] = R.cursor;
     t->part_overflow = R.overflow;
     st = insert_finish(t, S, n, PB, cap_u, mode, forced_cap, tmp, n_new_out, m);
-    t->part_overflow = nullptr;
+    t->part_overflow = nullptr; t->batch_nodup = false;
     if (st != KH_RETRY_EXACT) return st;
   }
   return fail(t, KH_ERR_HIP, "internal: exact partition reported a slot overflow");
@@ -705,6 +707,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST;
     F.base_size = 0;
     F.n_total = n;
+    F.nodup = (t->batch_nodup && mode != INS_UPDATE && !getenv("KH_DISABLE_NODUP")) ? 1 : 0;
     // giving up early only makes sense if a smaller capacity is possible at all (an insert never shrinks the table)
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
     FusedRun run;
@@ -1303,7 +1306,7 @@ kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t v
   t->kind = (int)kind; t->hash = (int)hash; t->device = device; t->seed = KhSeed{seed, 0u}; t->stream = nullptr;
   t->min_lf = min_lf; t->max_lf = max_lf; t->lsize = 0;
   t->cur = kNoSlots; t->spare = t->cur;
-  t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false; t->part_overflow = nullptr;
+  t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false; t->part_overflow = nullptr; t->batch_nodup = false;
   memset(&t->ins, 0, sizeof(t->ins));
   const uint64_t cap = next_pow2(capacity);
   if (alloc_slots(t, cap, t->cur) != KH_OK) { delete t; return KH_ERR_NOMEM; }

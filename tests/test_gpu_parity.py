@@ -1004,8 +1004,11 @@ def test_histogram_free_partition_and_its_fall_backs(oracle):
     (one key repeated 30000 times among 4e6 distinct ones) overflow a slot and the batch is redone with exact offsets."""
     n = 4_000_000                                   # capacity 2^23: 4096 partitions (two partition passes) of ~977 records
     keys = W.distinct_u64(n, seed=123); vals = np.arange(n, dtype=np.uint32)
-    for variant in ("distinct", "duplicate_heavy", "hidden_skew"):
-        if variant == "duplicate_heavy":
+    for variant in ("distinct", "few_hidden_duplicates", "duplicate_heavy", "hidden_skew"):
+        if variant == "few_hidden_duplicates":      # 300 keys given twice, none at a sampled position: the speculative no-fold build must notice
+            k = keys.copy(); v = vals
+            k[(n // 65536) * np.arange(1000, 1300) + 3] = keys[(n // 65536) * np.arange(5000, 5300) + 7]
+        elif variant == "duplicate_heavy":
             k, v = W.w1_benchmark_hashtables(n, seed=9)
         elif variant == "hidden_skew":
             k = keys.copy(); k[(n // 65536) * np.arange(30_000) + 1] = keys[7]; v = vals      # between the sample's positions (stride n // 65536)
@@ -1017,7 +1020,9 @@ def test_histogram_free_partition_and_its_fall_backs(oracle):
         p = g.profile()
         assert "k_sample_dups" in p
         if variant == "distinct":
-            assert "k_part_hist" not in p and p["k_part_scatter"][0] == 2, p
+            assert "k_part_hist" not in p and p["k_part_scatter"][0] == 2 and "k_dedup" not in p, p
+        elif variant == "few_hidden_duplicates":
+            assert "k_part_hist" not in p and p["k_part_scatter"][0] == 2 and "k_build_fused" in p and "k_dedup" in p, p     # fused attempt, then the general path
         elif variant == "duplicate_heavy":
             assert "k_part_hist" in p and p["k_part_scatter"][0] == 2, p
         else:
