@@ -40,6 +40,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# KH_BENCH_REHEARSAL=1: N ranks share GPU 0 and talk over gloo (RCCL refuses two ranks on one device).  Exercises the launcher, the
+# barriers, the sharded insert / find and the result reduction of the N > 1 path on a one-GPU box; the JSON line says "rehearsal".
+REHEARSAL = os.environ.get("KH_BENCH_REHEARSAL", "0") == "1"
 KEYS_LOAD_080 = 107_374_184        # size_t(float(2^27) * 0.8f): hashmap_robinhood.hpp:263; load exactly 0.800
 KEYS_PER_GPU_DIST = 100_000_000
 QUERIES_PER_GPU = 10_000_000
@@ -192,6 +195,8 @@ def visible_gpus():
 def launch(args, argv):
     n = args.gpus
     have = visible_gpus()
+    if REHEARSAL:              # every rank on device 0 over gloo: a dry run of the N > 1 control flow on a one-GPU box, never a measurement
+        have = max(have, n) if have >= 1 else have
     if have < n:
         print("[bench] --gpus %d requested but only %d GPU(s) visible: refusing to run fewer ranks than asked for" % (n, have),
               file=sys.stderr, flush=True)
@@ -256,6 +261,8 @@ def run_rank(args):
     import torch
     import kmerhash_amd as kh
     from kmerhash_amd import dist as khd
+    if REHEARSAL:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         print("[bench] rank %d: device %d not visible" % (rank, local_rank), file=sys.stderr, flush=True)
         return 2
@@ -267,7 +274,10 @@ def run_rank(args):
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if REHEARSAL:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             print("[bench] process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus), file=sys.stderr, flush=True)
             return 2
@@ -406,7 +416,7 @@ def run_rank(args):
                        "keys_per_gpu": args.keys, "queries_per_gpu": args.queries, "table": "hashmap_robinhood_doubling",
                        "hash": args.hash, "max_load_factor": 0.8, "min_load_factor": 0.35, "final_load": load,
                        "exchange_pieces": args.chunks if distributed else None},
-            "rccl_ranks": rccl_ranks,
+            "rccl_ranks": rccl_ranks if not REHEARSAL else 0, "rehearsal": REHEARSAL,
             "inserts_per_s": ins_rate, "finds_per_s": find_rate,
             "insert_ms": ins_mean, "find_ms": find_mean,
             "roofline": {"bound": "hbm", "op": "insert", "unit": "GB/s", "peak": HBM_PEAK_GBS,

@@ -46,3 +46,19 @@ def test_more_gpus_than_visible_fails_loudly():
 def test_rank_refuses_world_size_mismatch():
     r = _run(["--gpus", "4", "--no-cpu-baseline"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 4" in r.stderr and r.stdout.strip() == ""
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_rank_control_flow_rehearsal_on_one_gpu():
+    """the N > 1 path of bench.py end to end -- launcher, rank processes, barriers, pipelined sharded insert, sharded find, the result
+    reductions and assertions -- with both ranks on GPU 0 over gloo (KH_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device)"""
+    import json
+    r = _run(["--gpus", "2", "--keys", "3000000", "--queries", "300000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+             {"KH_BENCH_REHEARSAL": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["config"]["exchange_pieces"] == 4
+    assert set(d["phases_ms_per_step_rank0"]) >= {"count_pass", "permute", "exchange", "feed", "build"}
