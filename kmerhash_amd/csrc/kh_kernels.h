@@ -209,7 +209,7 @@ __device__ __forceinline__ uint32_t kh_probe_items(const KhSlots& T, const uint6
 template <int KIND, int HASH, int OUT, bool XF>
 __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
   __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_wcnt[KH_Q_NB * KH_Q_ITEMS][KH_Q_THREADS / 64];
+  __shared__ __align__(16) uint32_t s_wcnt[KH_Q_NB * KH_Q_ITEMS][KH_Q_THREADS / 64];
   __shared__ unsigned long long s_prefix;
   __shared__ uint32_t s_val[(OUT == KH_FIND_COMPACT || OUT == KH_FIND_PAIRS) ? KH_Q_TILE : 1];      // values of the tile's hits (16 KB)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -266,22 +266,20 @@ __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
       }
     }
     if (OUT == KH_FIND_PERQUERY || OUT == KH_FIND_COUNT) continue;
-    // ---- ranks of the hits inside the tile (query order = (batch, item)-major, then lane)
-    uint32_t before[KH_Q_NB * KH_Q_ITEMS];
+    // ---- hits of the tile per (batch, item) and wave (query order = (batch, item)-major, then lane); the rank of every hit is
+    // derived from these counts again at the write-out (16 ranks kept in registers cost the fourth wave per SIMD)
+    static_assert(KH_Q_THREADS / 64 == 4, "s_wcnt rows are read as one uint4");
 #pragma unroll
     for (int j = 0; j < KH_Q_NB * KH_Q_ITEMS; ++j) {
       const unsigned long long m = __ballot((hit >> j) & 1u);
-      before[j] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       if (lane == 0) s_wcnt[j][wid] = (uint32_t)__popcll(m);
     }
     __syncthreads();
     uint32_t total = 0;
 #pragma unroll
     for (int j = 0; j < KH_Q_NB * KH_Q_ITEMS; ++j) {
-      uint32_t mine = total;
-#pragma unroll
-      for (uint32_t w2 = 0; w2 < KH_Q_THREADS / 64; ++w2) { const uint32_t c = s_wcnt[j][w2]; if (w2 < wid) mine += c; total += c; }
-      before[j] += mine;
+      const uint4 c = *reinterpret_cast<const uint4*>(&s_wcnt[j][0]);
+      total += c.x + c.y + c.z + c.w;
     }
     // ---- decoupled look-back (wave 0): exclusive prefix of this tile over the tiles before it
     if (wid == 0) {
@@ -325,19 +323,35 @@ __global__ __launch_bounds__(KH_Q_THREADS) void k_find(KhFindParams P) {
     }
     __syncthreads();
     const unsigned long long obase = s_prefix;
-    // the keys of the hits are read again (the batch's registers were reused; the tile's 32 KB of queries are L2-hot)
+    // the keys of the hits are read again (the batch's registers were reused; the tile's 32 KB of queries are L2-hot): four
+    // loads in flight per lane, clamped indices instead of a branch per item (which makes every load wait for the one before)
+    uint32_t run = 0;                               // hits of the tile in the (batch, item) rows before j
 #pragma unroll
-    for (int j = 0; j < KH_Q_NB * KH_Q_ITEMS; ++j) {
-      if ((hit >> j) & 1u) {
-        uint64_t key = P.q[base + (uint64_t)j * KH_Q_THREADS + tid];
-        if (XF && ((swapped >> j) & 1u)) key = kh_revcomp(key, P.seed.xk);        // the table holds the other strand's bit pattern
-        const unsigned long long o = obase + before[j];
-        if (OUT == KH_FIND_PAIRS) {
-          uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = s_val[j * KH_Q_THREADS + tid]; w.w = 0;
-          *reinterpret_cast<uint4*>(P.out_pairs16 + o * 16) = w;
-        } else {
-          P.out_keys[o] = key;
-          P.out_vals[o] = s_val[j * KH_Q_THREADS + tid];
+    for (int g = 0; g < KH_Q_NB * KH_Q_ITEMS; g += 4) {
+      uint64_t kk[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const uint64_t i = base + (uint64_t)(g + jj) * KH_Q_THREADS + tid;
+        kk[jj] = P.q[i < P.n ? i : P.n - 1];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = g + jj;
+        const unsigned long long m = __ballot((hit >> j) & 1u);
+        const uint4 c = *reinterpret_cast<const uint4*>(&s_wcnt[j][0]);
+        const uint32_t before = run + (wid > 0 ? c.x : 0u) + (wid > 1 ? c.y : 0u) + (wid > 2 ? c.z : 0u) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        run += c.x + c.y + c.z + c.w;
+        if ((hit >> j) & 1u) {
+          uint64_t key = kk[jj];
+          if (XF && ((swapped >> j) & 1u)) key = kh_revcomp(key, P.seed.xk);        // the table holds the other strand's bit pattern
+          const unsigned long long o = obase + before;
+          if (OUT == KH_FIND_PAIRS) {
+            uint4 w; w.x = (uint32_t)key; w.y = (uint32_t)(key >> 32); w.z = s_val[j * KH_Q_THREADS + tid]; w.w = 0;
+            *reinterpret_cast<uint4*>(P.out_pairs16 + o * 16) = w;
+          } else {
+            P.out_keys[o] = key;
+            P.out_vals[o] = s_val[j * KH_Q_THREADS + tid];
+          }
         }
       }
     }
@@ -535,6 +549,10 @@ __global__ __launch_bounds__(256) void k_compact_hits(const uint8_t* __restrict_
 // radix partition of a batch by (bit-reversed) chunk id.  Records travel as SoA (key, val, idx).
 // ---------------------------------------------------------------------------------------------
 struct KhTile { uint64_t beg; uint32_t len; uint32_t seg; };
+// 12-byte record (key, value) without the stream position: a batch whose sample showed no duplicate key, going into an empty
+// table, needs no first-occurrence order (every key is its own first occurrence; any duplicate the build meets sends the
+// batch back through the 16-byte path).  One dwordx3 access each: a quarter less partition traffic.
+struct KhRec12 { uint32_t klo, khi, val; };
 
 struct KhPartParams {
   const char* kbase; uint32_t kstride;     // input keys (stride 8 = SoA, 16 = pair array)
@@ -559,6 +577,7 @@ struct KhPartParams {
   uint64_t slot;
   uint64_t dump;                           // first record of the dump area in orec (KH_PART_TILE records)
   uint32_t* overflow;
+  // (k_part_scatter<HASH, true>: rec_in / orec hold KhRec12 records instead -- histogram-free mode only)
 };
 
 // partition id of a hash: chunk id at the partitioning capacity, bit-reversed so that the
@@ -623,10 +642,17 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_hist(KhPartParams P) {
 // records are staged in LDS in digit order and streamed out, so that consecutive lanes write consecutive
 // addresses (a direct scatter costs 4.8x the algorithmic write traffic in partial-sector writes: profiles/
 // round-1 PMC notes).
-template <int HASH>
+__device__ __forceinline__ void kh_rec_set(ulonglong2& r, uint64_t key, unsigned long long iv) { r = make_ulonglong2(key, iv); }
+__device__ __forceinline__ void kh_rec_set(KhRec12& r, uint64_t key, unsigned long long iv) { r.klo = (uint32_t)key; r.khi = (uint32_t)(key >> 32); r.val = (uint32_t)iv; }
+__device__ __forceinline__ void kh_rec_get(const ulonglong2& r, uint64_t& key, unsigned long long& iv) { key = r.x; iv = r.y; }
+__device__ __forceinline__ void kh_rec_get(const KhRec12& r, uint64_t& key, unsigned long long& iv) { key = r.klo | ((uint64_t)r.khi << 32); iv = r.val; }
+template <bool R12> struct KhRecOf { typedef ulonglong2 type; };
+template <> struct KhRecOf<true> { typedef KhRec12 type; };
+template <int HASH, bool R12>
 __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P) {
+  typedef typename KhRecOf<R12>::type Rec;
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
-  __shared__ ulonglong2 lrec[KH_PART_STAGE];
+  __shared__ Rec lrec[KH_PART_STAGE];
   __shared__ uint16_t ld[KH_PART_STAGE];
   __shared__ uint32_t wtot[KH_PART_THREADS / 64];
   const uint32_t nb = P.nb;
@@ -637,31 +663,53 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
   const uint32_t ntiles = P.tiles ? *P.ntiles_dev : P.ntiles;
   if (blockIdx.x >= ntiles) return;
   KhTile d = kh_get_tile(P, blockIdx.x);
+  if (d.len == 0) return;
   for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) hist[i] = 0;
   __syncthreads();
   uint64_t key[KH_PART_ITEMS];
   unsigned long long iv[KH_PART_ITEMS];
   uint32_t dr[KH_PART_ITEMS];                   // digit << 16 | rank inside the digit (rank < 8192)
+  // every lane requests all its records before it looks at the first one (indices past the tile's end are clamped, not predicated:
+  // a branch per item makes the compiler wait for each load in turn -- 16 dependent HBM round trips per tile)
+  const uint32_t last = d.len - 1u;                 // (a tile holds at least one record)
+  if (P.rec_in) {
+    const Rec* src = reinterpret_cast<const Rec*>(P.rec_in) + d.beg;
+    Rec rr[KH_PART_ITEMS];
 #pragma unroll
-  for (int j = 0; j < KH_PART_ITEMS; ++j) {
-    uint32_t i = tid + j * KH_PART_THREADS;
-    if (i < d.len) {
-      if (P.rec_in) { const ulonglong2 rr = P.rec_in[d.beg + i]; key[j] = rr.x; iv[j] = rr.y; }
-      else {
-        key[j] = *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
-        iv[j] = ((unsigned long long)(P.idx_base + d.beg + i) << 32) |
-                (P.vbase ? *reinterpret_cast<const uint32_t*>(P.vbase + (d.beg + i) * P.vstride) : P.vconst);
+    for (int j = 0; j < KH_PART_ITEMS; ++j) { const uint32_t i = tid + j * KH_PART_THREADS; rr[j] = src[i < last ? i : last]; }
+#pragma unroll
+    for (int j = 0; j < KH_PART_ITEMS; ++j) kh_rec_get(rr[j], key[j], iv[j]);
+  } else {
+    const char* kb = P.kbase + d.beg * P.kstride;
+#pragma unroll
+    for (int j = 0; j < KH_PART_ITEMS; ++j) {
+      const uint32_t i = tid + j * KH_PART_THREADS, ic = i < last ? i : last;
+      key[j] = *reinterpret_cast<const uint64_t*>(kb + (uint64_t)ic * P.kstride);
+    }
+    if (P.vbase) {
+      const char* vb = P.vbase + d.beg * P.vstride;
+#pragma unroll
+      for (int j = 0; j < KH_PART_ITEMS; ++j) {
+        const uint32_t i = tid + j * KH_PART_THREADS, ic = i < last ? i : last;
+        iv[j] = *reinterpret_cast<const uint32_t*>(vb + (uint64_t)ic * P.vstride);
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < KH_PART_ITEMS; ++j) iv[j] = P.vconst;
+    }
+    if (!R12) {
+      const uint64_t pos0 = P.idx_base + d.beg;
+#pragma unroll
+      for (int j = 0; j < KH_PART_ITEMS; ++j) iv[j] |= (unsigned long long)(pos0 + tid + j * KH_PART_THREADS) << 32;
     }
   }
 #pragma unroll
   for (int j = 0; j < KH_PART_ITEMS; ++j) {
-    uint32_t i = tid + j * KH_PART_THREADS;
-    if (i < d.len) {
-      const uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
-      const uint32_t dg = (q >> P.shift) & (nb - 1);
-      dr[j] = (dg << 16) | atomicAdd(&hist[dg], 1u);
-    }
+    const uint32_t i = tid + j * KH_PART_THREADS;
+    const uint32_t q = kh_part_q(kh_hash64<HASH>(key[j], P.seed), P.PB);
+    const uint32_t dg = (q >> P.shift) & (nb - 1);
+    dr[j] = dg << 16;
+    if (i < d.len) dr[j] |= atomicAdd(&hist[dg], 1u);
   }
   __syncthreads();
   // exclusive scan of the digit counts (each thread owns nb/512 consecutive bins) + global reservation
@@ -706,7 +754,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
       if (i < d.len) {
         const uint32_t dg = dr[j] >> 16;
         const uint32_t s = loff[dg] + (dr[j] & 0xFFFFu) - r0;     // position in the tile's digit order, relative to this round
-        if (s < KH_PART_STAGE) { lrec[s] = make_ulonglong2(key[j], iv[j]); ld[s] = (uint16_t)dg; }
+        if (s < KH_PART_STAGE) { kh_rec_set(lrec[s], key[j], iv[j]); ld[s] = (uint16_t)dg; }
       }
     }
     if (r0 == 0) {
@@ -721,7 +769,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
     for (uint32_t s = tid; s < rl; s += KH_PART_THREADS) {
       const uint32_t dd = ld[s];
       const uint64_t pos = gbase[dd] + (r0 + s - loff[dd]);
-      P.orec[pos] = lrec[s];
+      reinterpret_cast<Rec*>(P.orec)[pos] = lrec[s];
     }
   }
 }
@@ -1004,6 +1052,7 @@ struct KhSrcSet {
   uint64_t slot[KH_MAX_SRC];             // != 0: histogram-free source: partition q = rec[s][q * slot, cur[s][q]) (clamped to the slot)
   const unsigned long long* cur[KH_MAX_SRC];
   uint32_t n;                            // number of sources (>= 1)
+  uint32_t rec12;                        // != 0 (one histogram-free source only): rec[0] holds KhRec12 records (key, value; no stream position)
   const uint64_t* merged_off;            // [nparts+1] sum over the sources of off[s][q]: where partition q's OUTPUT list starts
 };
 // per-workgroup view of partition q.  One source (every plain insert): the slice is addressed directly through a
@@ -1013,17 +1062,21 @@ struct KhSrcSet {
 // a dependent global load per record).
 struct KhSrcView {
   const ulonglong2* one;                 // != nullptr: single source, slice start
+  const KhRec12* one12;                  // != nullptr: single source of 12-byte records, slice start
   uint32_t m;                            // records of the partition
   uint32_t n;                            // sources
 };
+template <bool ALLOW12 = false>
 __device__ __forceinline__ KhSrcView kh_src_setup(const KhSrcSet& S, uint32_t q, const ulonglong2** s_ptr, uint32_t* s_cum) {
   KhSrcView V;
   V.n = S.n;
+  V.one12 = nullptr;
   if (S.n == 1) {
     if (S.slot[0]) {
       const uint64_t b = (uint64_t)q * S.slot[0];
       const uint64_t c = S.cur[0][q] - b;
       V.one = S.rec[0] + b;
+      if (ALLOW12 && S.rec12) { V.one = nullptr; V.one12 = reinterpret_cast<const KhRec12*>(S.rec[0]) + b; }
       V.m = (uint32_t)(c < S.slot[0] ? c : S.slot[0]);
       return V;
     }
@@ -1046,8 +1099,10 @@ __device__ __forceinline__ KhSrcView kh_src_setup(const KhSrcSet& S, uint32_t q,
   V.m = s_cum[S.n];
   return V;
 }
+template <bool ALLOW12 = false>
 __device__ __forceinline__ ulonglong2 kh_src_load(const KhSrcView& V, const ulonglong2* const* s_ptr, const uint32_t* s_cum, uint32_t i) {
   if (V.one) return V.one[i];
+  if (ALLOW12 && V.one12) { const KhRec12 r = V.one12[i]; return make_ulonglong2(r.klo | ((uint64_t)r.khi << 32), (unsigned long long)r.val); }
   uint32_t s = 0;
   while (s + 1 < V.n && i >= s_cum[s + 1]) ++s;
   return s_ptr[s][i];
@@ -1587,13 +1642,12 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
 #pragma unroll
       for (uint32_t it = 0; it < NS; ++it) {
         const uint32_t t = it * KH_CHUNK_THREADS + tid;
-        w[it] = make_uint4(0u, 0u, 0u, 0u);
-        if (t < KH_L + 128u) w[it] = kh_slot_ld(R.Old.s + ((S + t) & mask_o));
+        w[it] = kh_slot_ld(R.Old.s + ((S + (t < KH_L + 128u ? t : KH_L + 127u)) & mask_o));      // (clamped, not predicated: loads stay in flight together)
       }
 #pragma unroll
       for (uint32_t it = 0; it < NS; ++it) {
         const uint64_t sl = (S + it * KH_CHUNK_THREADS + tid) & mask_o;
-        const uint32_t inf = w[it].w & 0xFFu;
+        const uint32_t inf = it * KH_CHUNK_THREADS + tid < KH_L + 128u ? (w[it].w & 0xFFu) : 0u;
         bool take = false;
         uint32_t hrel = 0;
         const uint64_t key = kh_slot_key(w[it]);
@@ -1675,7 +1729,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   // (record indices travel as 11-bit fields next to a 5-bit distance code, 0xFFFF = empty slot: index 2047 stays unused)
   if (SRC == 0) {
     const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
-    const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
+    const KhSrcView V = kh_src_setup<true>(P.src, q, s_ptr, s_cum);
     m = V.m;
     vote_rec = m;
     const bool aborted = s_abort != 0;
@@ -1690,12 +1744,25 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     // ---- de-dup (as k_dedup, single round)
     const bool nodup = P.nodup && c != 0;            // (chunk 0 is parked, not placed here: it keeps the fold)
     if (!nodup) for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
-    {   // all (<= 4) records of a lane are requested before the first one is stored: one HBM round trip, not four
+    if (m) {   // all (<= 4) records of a lane are requested before the first one is stored: one HBM round trip, not four.  (Clamped
+      // indices, no branch per record: with one the compiler waits for every load in turn.)
       ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
+      const uint32_t last = m - 1u;
+      if (V.one12) {
+        KhRec12 r3[KH_DD_M / KH_CHUNK_THREADS];
 #pragma unroll
-      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-        const uint32_t i = it * KH_CHUNK_THREADS + tid;
-        if (i < m) rr[it] = kh_src_load(V, s_ptr, s_cum, i);
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; r3[it] = V.one12[i < last ? i : last]; }
+#pragma unroll
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) rr[it] = make_ulonglong2(r3[it].klo | ((uint64_t)r3[it].khi << 32), (unsigned long long)r3[it].val);
+      } else if (V.one) {
+#pragma unroll
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; rr[it] = V.one[i < last ? i : last]; }
+      } else {
+#pragma unroll
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+          const uint32_t i = it * KH_CHUNK_THREADS + tid;
+          if (i < m) rr[it] = kh_src_load(V, s_ptr, s_cum, i);
+        }
       }
 #pragma unroll
       for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
@@ -1731,12 +1798,18 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       }
       return;
     }
-    {   // (all of a lane's records requested before the first one is stored)
+    if (V.m) {   // (all of a lane's records requested before the first one is stored: clamped indices, as above)
       ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
+      const uint32_t last = V.m - 1u;
+      if (V.one) {
 #pragma unroll
-      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-        const uint32_t i = it * KH_CHUNK_THREADS + tid;
-        if (i < V.m) rr[it] = kh_src_load(V, s_ptr, s_cum, i);
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; rr[it] = V.one[i < last ? i : last]; }
+      } else {
+#pragma unroll
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+          const uint32_t i = it * KH_CHUNK_THREADS + tid;
+          if (i < V.m) rr[it] = kh_src_load(V, s_ptr, s_cum, i);
+        }
       }
 #pragma unroll
       for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
@@ -1801,6 +1874,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   if (c == 0) {     // circular table: chunk 0 follows the last chunk -> publish, park, and leave the placement to the tail launch
     if (tid == 0) {
       if (!early) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+      // (12-byte records carry no stream position: a fold that merged equal keys could not tell which came first)
+      if (SRC == 0 && P.src.rec12 && n_c != m) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
       __hip_atomic_store(&P.pub[0], VALID | ((unsigned long long)spill0 << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       P.maxidx[0] = s_max;
       s_x = 0;

@@ -492,6 +492,7 @@ struct Partitioned {
   uint64_t slot;                                // != 0: histogram-free layout: partition q = rec[q * slot, cursor[q])
   const unsigned long long* cursor;
   uint32_t* overflow;                           // device flag: a partition outgrew its slot (the batch must be redone with exact offsets)
+  bool rec12;                                   // rec holds 12-byte (key, value) records (histogram-free layout only)
 };
 // slot of a histogram-free partition with mean m records: m + 7 sigma (hashed keys: Poisson) + a little
 inline uint64_t slack_slot(double mean) { return (uint64_t)(mean + 7.0 * std::sqrt(mean) + 16.0); }
@@ -506,9 +507,9 @@ inline uint64_t part_buffer_records(uint64_t n, uint32_t PB, bool allow_slack) {
 // stream position of the first pair (pairs fed before it in a streamed insert).  Asynchronous on the table's stream.
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
                           uint32_t vconst, uint64_t n, uint64_t idx_base, uint32_t PB, ulonglong2* tmp, ulonglong2* fin, Partitioned& out,
-                          bool allow_slack = false) {
+                          bool allow_slack = false, bool rec12 = false) {
   const uint32_t nparts = 1u << PB;
-  out.slot = 0; out.cursor = nullptr; out.overflow = nullptr;
+  out.slot = 0; out.cursor = nullptr; out.overflow = nullptr; out.rec12 = false;
   if (part_buffer_records(n, PB, allow_slack) != n) {
     // ---- histogram-free two-pass partition: hashed keys fill the 2^PB partitions evenly, so every partition
     // gets a fixed slot of mean + 7 sigma records and the passes reserve space with their cursors alone: no histogram sweep
@@ -529,7 +530,8 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
     P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.cursor = cur1; P.orec = tmp; P.slot = slot1; P.overflow = ovf; P.dump = slot * nparts;
     { Launch L(t, "k_part_scatter");
-      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
+      if (rec12) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, true>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
+      else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); } }
     { Launch L(t, "k_make_tiles");
       hipLaunchKernelGGL(k_make_tiles, dim3(1), dim3(1024), 0, t->stream, (const uint64_t*)nullptr, nb1, tiles, ntiles_dev, (const unsigned long long*)cur1, slot1); }
     KhPartParams Q = P;
@@ -537,10 +539,11 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
     Q.shift = 0; Q.nb = nb2; Q.cursor = cur2; Q.orec = fin; Q.slot = slot;
     { Launch L(t, "k_part_scatter");
-      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
+      if (rec12) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, true>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
+      else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); } }
     HIPCHK(hipGetLastError());
     out.rec = fin; out.part_off = starts; out.PB = PB; out.nparts = nparts; out.spare = tmp;
-    out.slot = slot; out.cursor = cur2; out.overflow = ovf;
+    out.slot = slot; out.cursor = cur2; out.overflow = ovf; out.rec12 = rec12;
     return KH_OK;
   }
   ulonglong2* ar = nullptr; ulonglong2* br = fin;
@@ -591,7 +594,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     HIPCHK(hipMemcpyAsync(cur1, off1, sizeof(uint64_t) * nb1, hipMemcpyDeviceToDevice, t->stream));
   }
   { Launch L(t, "k_part_scatter");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
   if (B2 == 0) {
     out.rec = ar; out.part_off = off1; out.PB = PB; out.nparts = nparts;
     out.spare = tmp;
@@ -614,7 +617,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   }
   HIPCHK(hipMemcpyAsync(cur2, off2, sizeof(uint64_t) * nparts, hipMemcpyDeviceToDevice, t->stream));
   { Launch L(t, "k_part_scatter");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
+    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
   HIPCHK(hipGetLastError());
   out.rec = br; out.part_off = off2; out.PB = PB; out.nparts = nparts;
   out.spare = tmp;
@@ -642,6 +645,14 @@ bool g_disable_fused = getenv("KH_DISABLE_FUSED_BUILD") != nullptr;   // test ho
 const kh_status KH_RETRY_EXACT = static_cast<kh_status>(100);      // internal: a histogram-free partition overflowed a slot
 kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64_t cap_u, int mode, uint64_t forced_cap,
                         ulonglong2* spare, uint64_t* n_new_out, uint64_t list_cap = 0);
+
+// does the one-launch bulk build (k_build_fused, SRC 0) apply, and may it skip the LDS fold after a duplicate-free sample?
+inline bool fused_build_applies(const kh_table* t, uint64_t cap_u, uint32_t PB) {
+  return t->lsize == 0 && cap_u >= 2 * (uint64_t)KH_L && t->max_lf <= 0.9f && PB == log2u(cap_u >> KH_LB) && !g_disable_fused;
+}
+inline bool nodup_build_applies(const kh_table* t, uint64_t cap_u, uint32_t PB, int mode) {
+  return fused_build_applies(t, cap_u, PB) && t->batch_nodup && mode != INS_UPDATE && !getenv("KH_DISABLE_NODUP");
+}
 
 // core of insert/update for one batch of device-resident input (n < 2^32 - 16)
 kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
@@ -671,14 +682,20 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     const bool slack = attempt == 0;          // histogram-free first; exact offsets if a partition outgrew its slot (skewed keys)
     const uint64_t m = part_buffer_records(n, PB, slack);
     if (!slack && attempt == 1) { t->blk = keep_blk; t->off = keep_off; }
+    // no duplicate in the sample and an empty table ahead of the one-launch build: the records need no stream position
+    // (12 bytes instead of 16); whatever that build cannot take (a duplicate after all, a dense chunk) repeats the batch
+    const bool rec12 = slack && t->batch_nodup && nodup_build_applies(t, cap_u, PB, mode);
     ulonglong2 *tmp, *fin;
-    TAKE(tmp, ulonglong2, m); TAKE(fin, ulonglong2, m);
+    { char *a, *b; const size_t rb = rec12 ? sizeof(KhRec12) : sizeof(ulonglong2);
+      TAKE(a, char, m * rb); TAKE(b, char, m * rb);
+      tmp = reinterpret_cast<ulonglong2*>(a); fin = reinterpret_cast<ulonglong2*>(b); }
     Partitioned R;
-    kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R, slack);
+    kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R, slack, rec12);
     if (st != KH_OK) return st;
     KhSrcSet S;
     memset(&S, 0, sizeof(S));
     S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off; S.slot[0] = R.slot; S.cur[0] = R.cursor;
+    S.rec12 = R.rec12 ? 1u : 0u;
     t->part_overflow = R.overflow;
     st = insert_finish(t, S, n, PB, cap_u, mode, forced_cap, tmp, n_new_out, m);
     t->part_overflow = nullptr; t->batch_nodup = false;
@@ -696,7 +713,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   struct { uint32_t nparts; } R; R.nparts = nparts;
   // ---- fused bulk build: empty table, moderate load factor, at least two chunks.  Speculates that the capacity the
   // reference's rule yields equals cap_u (true when the batch holds few duplicates); otherwise falls through.
-  if (t->lsize == 0 && cap_u >= 2 * (uint64_t)KH_L && t->max_lf <= 0.9f && PB == log2u(cap_u >> KH_LB) && !g_disable_fused) {
+  if (fused_build_applies(t, cap_u, PB)) {
     const uint32_t nch = (uint32_t)(cap_u >> KH_LB);
     KhSlots nw;
     st = fresh_slots(t, cap_u, nw);
@@ -707,7 +724,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST;
     F.base_size = 0;
     F.n_total = n;
-    F.nodup = (t->batch_nodup && mode != INS_UPDATE && !getenv("KH_DISABLE_NODUP")) ? 1 : 0;
+    F.nodup = nodup_build_applies(t, cap_u, PB, mode) ? 1 : 0;
     // giving up early only makes sense if a smaller capacity is possible at all (an insert never shrinks the table)
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
     FusedRun run;
@@ -715,9 +732,10 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     if (t->part_overflow && (uint32_t)t->hpin[30]) { retire_slots(t, nw); return KH_RETRY_EXACT; }
     unsigned long long* totals = run.totals;
     const uint64_t fd = t->hpin[0];
-    const uint64_t flast = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
+    // (12-byte records: accepted only if all n keys were distinct, so the last call is the last first occurrence)
+    const uint64_t flast = (mode == INS_PLUS || S.rec12) ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
     const uint32_t* ff = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 64);
-    bool bad = false;
+    bool bad = S.rec12 && fd != n;
     for (int i = 0; i < KH_NFLAGS; ++i) bad = bad || ff[i] != 0;
     if (!bad && capacity_after(t, t->cur.cap, t->lsize, n, fd, flast) == cap_u) {
       KhSlots old = t->cur;
@@ -745,7 +763,9 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
               reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[1], reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[0],
               reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[2]);
     retire_slots(t, nw);      // speculation failed (duplicates, skew): the buffer becomes the spare, general path below
+    if (S.rec12) return KH_RETRY_EXACT;      // (the general path needs the stream positions: repartition with 16-byte records)
   }
+  if (S.rec12) return fail(t, KH_ERR_HIP, "internal: 12-byte records outside the bulk build");
   // ---- fused insert into a NON-empty Robin Hood table: every chunk stages its current elements (home from the info byte)
   // next to the batch's records of the same chunk, folds them together (an element of the table beats every record), and
   // lays the chunk out -- no membership probes at random into HBM (k_dedup), no separate re-layout.  Speculates, like the
