@@ -974,6 +974,44 @@ __device__ __forceinline__ KhMP kh_block_scan_mp(KhMP v, KhMP* s_wtot, KhMP* tot
 }
 
 
+// 32-bit form for one chunk (positions < 2^13, counts < 2^12): half the cross-lane traffic of the 64-bit scan.  s_wtot must not be
+// in use by an earlier call of the same workgroup (no barrier in front of its stores).
+struct KhMP32 { int A; int n; };
+#define KH_MP32_NEG (-(1 << 28))
+__device__ __forceinline__ KhMP32 kh_mp_combine(KhMP32 first, KhMP32 then) {
+  KhMP32 r;
+  const int a = first.A + then.n;
+  r.A = then.A > a ? then.A : a;
+  r.n = first.n + then.n;
+  return r;
+}
+__device__ __forceinline__ KhMP32 kh_block_scan_mp32(KhMP32 v, KhMP32* s_wtot, KhMP32* total) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  KhMP32 incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    KhMP32 o;
+    o.A = __shfl_up(incl.A, off, 64);
+    o.n = __shfl_up(incl.n, off, 64);
+    if (lane >= (uint32_t)off) incl = kh_mp_combine(o, incl);
+  }
+  KhMP32 excl;
+  excl.A = __shfl_up(incl.A, 1, 64);
+  excl.n = __shfl_up(incl.n, 1, 64);
+  if (lane == 0) { excl.A = KH_MP32_NEG; excl.n = 0; }
+  if (lane == 63) s_wtot[wid] = incl;
+  __syncthreads();
+  KhMP32 wpre; wpre.A = KH_MP32_NEG; wpre.n = 0;
+  KhMP32 t = wpre;
+  for (uint32_t w = 0; w < nw; ++w) {
+    const KhMP32 x = s_wtot[w];
+    if (w < wid) wpre = kh_mp_combine(wpre, x);
+    t = kh_mp_combine(t, x);
+  }
+  *total = t;
+  return kh_mp_combine(wpre, excl);
+}
+
 // wave-aggregated append: lanes with `want` get consecutive positions from *counter (one LDS atomic per wave)
 __device__ __forceinline__ uint32_t kh_wave_append(bool want, uint32_t* counter) {
   const unsigned long long m = __ballot(want);
@@ -1693,6 +1731,12 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
   return *n_staged;
 }
 
+#ifdef KH_TRACE
+__device__ unsigned long long kh_trace[512 * 12];
+#define KH_STAMP(i) do { if (SRC == 0 && threadIdx.x == 0 && blockIdx.x >= 20000 && blockIdx.x < 20512) kh_trace[(blockIdx.x - 20000) * 12 + (i)] = clock64(); } while (0)
+#else
+#define KH_STAMP(i)
+#endif
 template <int KIND, int HASH, int SRC>
 __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams P) {
   __shared__ unsigned long long lk[KH_DD_M];
@@ -1701,7 +1745,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   // the chunk image is kept as 16-bit entries (11-bit index into the staged records | 5-bit distance code; 0xFFFF = empty slot): 4.3 KB instead of the
   // 28 KB of a (key, value, info) image, which keeps the kernel at 53.7 KB of LDS = 3 workgroups per CU
   __shared__ __align__(8) uint16_t simg[KH_L + KH_FSPILL];
-  __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
+  __shared__ KhMP32 s_wtot[KH_CHUNK_THREADS / 64];
   __shared__ uint32_t s_chunk, s_x, s_max, s_abort;
   __shared__ long long s_pend;
   static_assert(KH_HS >= 2 * KH_L, "set[] is reused as cnt/fill + start");
@@ -1710,6 +1754,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   const uint32_t tid = threadIdx.x;
   const uint64_t cap = P.New.cap, mask_n = cap - 1;
   const uint32_t nch = (uint32_t)(cap >> KH_LB);          // host guarantees cap >= 2 * KH_L
+  KH_STAMP(0);
   if (tid == 0) {
     s_chunk = blockIdx.x;
     s_max = 0;
@@ -1731,6 +1776,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
     const KhSrcView V = kh_src_setup<true>(P.src, q, s_ptr, s_cum);
     m = V.m;
+    KH_STAMP(1);
     vote_rec = m;
     const bool aborted = s_abort != 0;
     if (m >= KH_DD_M || aborted) {     // does not fit the staging area / speculation given up: general path
@@ -1779,6 +1825,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) if (it * KH_CHUNK_THREADS + tid < m) rep_mask |= 1u << it;
     } else rep_mask = kh_dd_fold(lk, liv, set, m, P.mode, P.seed.xk);
     __syncthreads();
+    KH_STAMP(2);
   } else if (SRC == 2) {
     // ---- insert into a non-empty table: the chunk's current elements + the batch's records of this chunk, folded together
     const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
@@ -1857,20 +1904,22 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   my_max = kh_wave_max(my_max);
   if ((tid & 63) == 0 && my_max) atomicMax(&s_max, my_max);
   __syncthreads();
+  KH_STAMP(3);
   uint32_t cb[KH_HOMES_PER_THREAD];
-  KhMP v; v.A = KH_MP_NEG; v.n = 0;
+  KhMP32 v; v.A = KH_MP32_NEG; v.n = 0;
 #pragma unroll
   for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
     const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
     cb[j] = cnt[b];
-    KhMP h; h.A = (long long)b + cb[j]; h.n = cb[j];
+    KhMP32 h; h.A = (int)(b + cb[j]); h.n = (int)cb[j];
     v = kh_mp_combine(v, h);
   }
-  KhMP total;
-  const KhMP excl = kh_block_scan_mp(v, s_wtot, &total);
+  KhMP32 total;
+  const KhMP32 excl = kh_block_scan_mp32(v, s_wtot, &total);
   const uint32_t n_c = (uint32_t)total.n;
   const long long spill0 = total.A > (long long)KH_L ? total.A - (long long)KH_L : 0;
   const bool early = n_c + KH_XB <= KH_L;
+  KH_STAMP(4);
   if (c == 0) {     // circular table: chunk 0 follows the last chunk -> publish, park, and leave the placement to the tail launch
     if (tid == 0) {
       if (!early) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
@@ -1927,6 +1976,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     P.maxidx[c] = s_max;
   }
   __syncthreads();
+  KH_STAMP(5);
   // ---- placement with the carry-in (as k_chunk_place)
   const long long xr = (long long)s_x;
   long long p = excl.A > xr + excl.n ? excl.A : xr + excl.n;
@@ -1940,13 +1990,16 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   }
   if (tid == KH_CHUNK_THREADS - 1) s_pend = p;
   __syncthreads();
+  uint32_t pr[KH_DD_M / KH_CHUNK_THREADS];       // slot (relative to the chunk) every record of this lane went to
 #pragma unroll
   for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+    pr[it] = 0;
     if ((rep_mask >> it) & 1u) {
       const uint32_t x = it * KH_CHUNK_THREADS + tid;
       const uint32_t b = hb[it];
       const uint32_t r = atomicAdd(&cnt[b], 1u);
       const uint32_t prel = start[b] + r;
+      pr[it] = prel;
       uint32_t dist = prel - b;
       if (KIND == KHK_RH && dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
       if (prel < KH_L + KH_FSPILL) simg[prel] = (uint16_t)(x | ((dist < 31u ? dist : 31u) << 11));   // record index | distance code
@@ -1954,29 +2007,56 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     }
   }
   __syncthreads();
+  KH_STAMP(6);
   if (SRC == 0 && P.nodup && c != 0) {
     // equal keys share their home bucket, hence sit in one group of consecutive slots [start[b], start[b] + cnt[b]): every
-    // element compares itself with the elements of its group behind it (groups hold ~1 element, rarely more than 4)
+    // element compares itself with the elements of its group BEHIND it (0.4 of them on average at load 0.8; walking the whole
+    // group to find oneself first made this check a quarter of the chunk's time)
     bool dup = false;
+    uint32_t gend[KH_DD_M / KH_CHUNK_THREADS];                      // pr[it] walks over the slots behind the record up to gend[it]
+    unsigned long long mykey[KH_DD_M / KH_CHUNK_THREADS];
 #pragma unroll
     for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      gend[it] = 0;
       if ((rep_mask >> it) & 1u) {
-        const uint32_t x = it * KH_CHUNK_THREADS + tid, b = hb[it];
-        const uint32_t g0 = start[b], g1 = g0 + cnt[b];
-        if (g1 > KH_L + KH_FSPILL) dup = true;                       // part of the group went past the image: cannot be checked here
-        else {
-          const unsigned long long key = lk[x];
-          bool after = false;
-          for (uint32_t sidx = g0; sidx < g1; ++sidx) {
-            const uint32_t xo = simg[sidx] & 0x7FFu;
-            if (xo == x) after = true;
-            else if (after && kh_keq(lk[xo], key, P.seed.xk)) dup = true;
-          }
+        const uint32_t b = hb[it];
+        gend[it] = start[b] + cnt[b];
+        if (gend[it] > KH_L + KH_FSPILL) { dup = true; gend[it] = 0; }       // part of the group went past the image: cannot be checked here
+      }
+      ++pr[it];
+      mykey[it] = lk[it * KH_CHUNK_THREADS + tid];
+    }
+    // the first KH_DUPK elements behind every record are looked up without a branch (all LDS reads of a lane in flight together:
+    // two dependent LDS latencies for the whole step); only groups longer than that (one bucket in 700 at load 0.8) enter the loop
+    constexpr uint32_t KH_DUPK = 3;
+    uint32_t ei[KH_DD_M / KH_CHUNK_THREADS][KH_DUPK];
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it)
+#pragma unroll
+      for (uint32_t d = 0; d < KH_DUPK; ++d) ei[it][d] = simg[pr[it] + d < gend[it] ? pr[it] + d : 0u] & 0x7FFu;
+    bool more = false;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+#pragma unroll
+      for (uint32_t d = 0; d < KH_DUPK; ++d)
+        if (kh_keq(lk[ei[it][d]], mykey[it], P.seed.xk) && pr[it] + d < gend[it]) dup = true;
+      pr[it] += KH_DUPK;
+      more = more || pr[it] < gend[it];
+    }
+    while (__any(more)) {
+      more = false;
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+        if (pr[it] < gend[it]) {
+          if (kh_keq(lk[simg[pr[it]] & 0x7FFu], mykey[it], P.seed.xk)) dup = true;
+          ++pr[it];
+          more = more || pr[it] < gend[it];
         }
       }
     }
     if (__any(dup) && (tid & 63) == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
   }
+  KH_STAMP(7);
   long long pend = s_pend;
   if (pend < (long long)KH_L) pend = KH_L;
   const uint32_t lo = (uint32_t)xr;
@@ -2000,6 +2080,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       kh_slot_st(dst, key, (uint32_t)liv[x], ib);      // one coalesced 16-byte store per slot: key, value and info byte together
     }
   }
+  KH_STAMP(8);
 }
 
 // carry-in of chunk 0 = run-over of the last chunk (circular table)

@@ -1929,3 +1929,7 @@ kh_status kh_profile_dump(kh_table* t, char* buf, uint64_t cap) {
 }
 
 }  // extern "C"
+
+#ifdef KH_TRACE
+extern "C" int kh_debug_trace(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(kh_trace), sizeof(unsigned long long) * 512 * 12); }
+#endif
