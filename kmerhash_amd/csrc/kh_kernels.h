@@ -1210,6 +1210,27 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
       __syncthreads();
       for (;;) {
         // ---- refill: stream sub-tiles of KH_CHUNK_THREADS records while a whole sub-tile still fits
+        if (R == 1 && V.one) {
+          // one class, one source (every plain insert): the next records go to the staging area as they come, up to four per
+          // lane requested together (one HBM round trip for a partition of ~1500 records, not one per sub-tile of 512; clamped
+          // indices, no branch per record)
+          const uint32_t room = ((KH_DD_M - D) / KH_CHUNK_THREADS) * KH_CHUNK_THREADS;
+          const uint32_t take_n = m - pos < room ? m - pos : room;
+          if (take_n) {                                    // (an empty partition has nothing to read: m - 1 would wrap)
+            ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
+            const uint32_t last = m - 1u;
+#pragma unroll
+            for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = pos + it * KH_CHUNK_THREADS + tid; rr[it] = V.one[i < last ? i : last]; }
+#pragma unroll
+            for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+              const uint32_t j = it * KH_CHUNK_THREADS + tid;
+              if (j < take_n) { lk[D + j] = rr[it].x; liv[D + j] = rr[it].y; }
+            }
+          }
+          pos += take_n;
+          ns = D + take_n;
+          __syncthreads();
+        } else {
         if (tid == 0) n_staged = 0;
         __syncthreads();
         do {
@@ -1228,6 +1249,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           ns = D + n_staged;
           __syncthreads();        // every lane has read the count before the next sub-tile's appends move it
         } while (pos < m && ns + KH_CHUNK_THREADS <= KH_DD_M);
+        }
         // ---- fold duplicates into their representative; rep_mask: which of this lane's records are representatives
         for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
         __syncthreads();
