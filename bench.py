@@ -400,6 +400,18 @@ def run_rank(args):
                 path_traffic = pm.get("_insert_path", {}).get("hbm_bytes_per_batch")
         except Exception:
             traffic = None
+        # the find path against the MEASURED random-access rate of this GPU (BASELINE.json's metric: "% HBM random-access roofline"):
+        # memory read requests per query (PMC, recorded) x finds/s over the rate at which the device serves random 64-byte sector
+        # reads of a table-sized buffer (scripts/random_access_roofline.hip, recorded)
+        ra = None
+        try:
+            rj = json.load(open(os.path.join(ROOT, "profiles", "%s_random_access.json" % tag)))
+            touches = find_rate / world * rj["k_find_rdreq_per_query"]
+            ra = {"sector_touches_per_query_pmc": rj["k_find_rdreq_per_query"], "achieved_touches_per_s": touches,
+                  "measured_peak_touches_per_s": rj["peak_used"], "frac": touches / rj["peak_used"],
+                  "source": "profiles/%s_random_access.json" % tag}
+        except Exception:
+            ra = None
         load = state[2] / state[3]
         out = {
             "metric": "kmer_inserts_plus_finds_per_sec",
@@ -428,7 +440,8 @@ def run_rank(args):
                                     "sector_frac": ins_rate / world * B_INSERT_SECTOR / 1e9 / HBM_PEAK_GBS, "sector_bytes_per_op": B_INSERT_SECTOR,
                                     "hbm_bytes_per_batch_pmc": path_traffic},
                          "find": {"achieved": find_gbs, "frac": find_gbs / HBM_PEAK_GBS, "bytes_per_op": B_FIND_HIT,
-                                  "sector_frac": find_rate / world * B_FIND_SECTOR / 1e9 / HBM_PEAK_GBS, "sector_bytes_per_op": B_FIND_SECTOR},
+                                  "sector_frac": find_rate / world * B_FIND_SECTOR / 1e9 / HBM_PEAK_GBS, "sector_bytes_per_op": B_FIND_SECTOR,
+                                  "random_access": ra},
                          "traffic": traffic, "traffic_source": traffic_src,
                          "dominant_kernel": {"name": dom, "avg_launch_ms": per_launch_ms, "launches_per_step": launches / args.steps,
                                              "hbm_bytes_per_launch_pmc": traffic,

@@ -1137,6 +1137,12 @@ __device__ __forceinline__ KhSrcView kh_src_setup(const KhSrcSet& S, uint32_t q,
   V.m = s_cum[S.n];
   return V;
 }
+// several sources: where record i of the partition lives (the loads themselves are issued by the caller, all of a lane's together)
+__device__ __forceinline__ const ulonglong2* kh_src_addr(const KhSrcView& V, const ulonglong2* const* s_ptr, const uint32_t* s_cum, uint32_t i) {
+  uint32_t s = 0;
+  while (s + 1 < V.n && i >= s_cum[s + 1]) ++s;
+  return s_ptr[s] + i;
+}
 template <bool ALLOW12 = false>
 __device__ __forceinline__ ulonglong2 kh_src_load(const KhSrcView& V, const ulonglong2* const* s_ptr, const uint32_t* s_cum, uint32_t i) {
   if (V.one) return V.one[i];
@@ -1210,8 +1216,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
       __syncthreads();
       for (;;) {
         // ---- refill: stream sub-tiles of KH_CHUNK_THREADS records while a whole sub-tile still fits
-        if (R == 1 && V.one) {
-          // one class, one source (every plain insert): the next records go to the staging area as they come, up to four per
+        if (R == 1) {
+          // one class (nearly always): the next records go to the staging area as they come, up to four per
           // lane requested together (one HBM round trip for a partition of ~1500 records, not one per sub-tile of 512; clamped
           // indices, no branch per record)
           const uint32_t room = ((KH_DD_M - D) / KH_CHUNK_THREADS) * KH_CHUNK_THREADS;
@@ -1219,8 +1225,16 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           if (take_n) {                                    // (an empty partition has nothing to read: m - 1 would wrap)
             ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
             const uint32_t last = m - 1u;
+            if (V.one) {
 #pragma unroll
-            for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = pos + it * KH_CHUNK_THREADS + tid; rr[it] = V.one[i < last ? i : last]; }
+              for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = pos + it * KH_CHUNK_THREADS + tid; rr[it] = V.one[i < last ? i : last]; }
+            } else {       // several feeds: find every record's source first, then request them together
+              const ulonglong2* pp[KH_DD_M / KH_CHUNK_THREADS];
+#pragma unroll
+              for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = pos + it * KH_CHUNK_THREADS + tid; pp[it] = kh_src_addr(V, s_ptr, s_cum, i < last ? i : last); }
+#pragma unroll
+              for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) rr[it] = *pp[it];
+            }
 #pragma unroll
             for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
               const uint32_t j = it * KH_CHUNK_THREADS + tid;
@@ -1826,11 +1840,11 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
 #pragma unroll
         for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; rr[it] = V.one[i < last ? i : last]; }
       } else {
+        const ulonglong2* pp[KH_DD_M / KH_CHUNK_THREADS];
 #pragma unroll
-        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-          const uint32_t i = it * KH_CHUNK_THREADS + tid;
-          if (i < m) rr[it] = kh_src_load(V, s_ptr, s_cum, i);
-        }
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; pp[it] = kh_src_addr(V, s_ptr, s_cum, i < last ? i : last); }
+#pragma unroll
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) rr[it] = *pp[it];
       }
 #pragma unroll
       for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
@@ -1874,11 +1888,11 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
 #pragma unroll
         for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; rr[it] = V.one[i < last ? i : last]; }
       } else {
+        const ulonglong2* pp[KH_DD_M / KH_CHUNK_THREADS];
 #pragma unroll
-        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-          const uint32_t i = it * KH_CHUNK_THREADS + tid;
-          if (i < V.m) rr[it] = kh_src_load(V, s_ptr, s_cum, i);
-        }
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; pp[it] = kh_src_addr(V, s_ptr, s_cum, i < last ? i : last); }
+#pragma unroll
+        for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) rr[it] = *pp[it];
       }
 #pragma unroll
       for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {

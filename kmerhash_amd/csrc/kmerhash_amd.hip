@@ -126,7 +126,7 @@ struct kh_table {
   std::string err;
   // streamed insert (kh_insert_begin / feed / end)
   struct {
-    bool active, fallback; int mode;
+    bool active, fallback, nodup; int mode;       // nodup: a sample of the FIRST feed found no duplicate key (the build then skips its fold, speculatively)
     uint64_t n_total, fed, cap_u; uint32_t PB;
     ulonglong2 *tmp, *fin;
     KhSrcSet S;
@@ -1417,7 +1417,7 @@ kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus) {
   t->ins.n_total = n_total;
   const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n_total ? n_total : 1, n_total, n_total ? n_total - 1 : 0);
   { kh_status ps = arena_prepare(t, n_total * 56 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 * (KH_MAX_SRC + 1) +
-                                    (n_total / KH_PART_TILE + 4096 * KH_MAX_SRC) * 16 + (size_t(4) << 20));
+                                    (n_total / KH_PART_TILE + 4096 * KH_MAX_SRC) * 16 + (size_t(8) << 20));
     if (ps != KH_OK) return ps; }
   const uint32_t PB = cu > KH_L ? log2u(cu >> KH_LB) : 0u;
   // the one-shot rule evaluation needs at most one pending doubling and 32-bit stream positions; otherwise the pieces are
@@ -1449,6 +1449,20 @@ kh_status kh_insert_feed(kh_table* t, const void* keys, const void* vals, uint64
     else HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(t->ins.stage_v + t->ins.fed), t->ins.mode == INS_PLUS ? 1 : 0, n, t->stream));
   } else {
     if (t->ins.S.n == KH_MAX_SRC) return fail(t, KH_ERR_UNSUPPORTED, "more than 16 feeds in one streamed insert");
+    if (t->ins.S.n == 0 && n >= KH_SAMPLE_N) {
+      // the first piece speaks for the batch: no duplicate among 65536 of its keys -> the one-launch build runs without its
+      // LDS fold and CHECKS instead (a duplicate met after all sends the batch down the general path, nothing is lost).  One
+      // host synchronisation per streamed insert, before anything else is in flight on this stream.
+      unsigned long long* sset; uint32_t* dups;
+      TAKE(sset, unsigned long long, KH_SAMPLE_SET); TAKE(dups, uint32_t, 1);
+      HIPCHK(hipMemsetAsync(sset, 0, sizeof(unsigned long long) * KH_SAMPLE_SET, t->stream));
+      HIPCHK(hipMemsetAsync(dups, 0, 4, t->stream));
+      { Launch L(t, "k_sample_dups");
+        hipLaunchKernelGGL(k_sample_dups, dim3(KH_SAMPLE_N / 256), dim3(256), 0, t->stream, reinterpret_cast<const char*>(dk), 8u, n, sset, dups); }
+      HIPCHK(hipMemcpyAsync(t->hpin + 31, dups, 4, hipMemcpyDeviceToHost, t->stream));
+      HIPCHK(hipStreamSynchronize(t->stream));
+      t->ins.nodup = (uint32_t)t->hpin[31] == 0u;
+    }
     Partitioned R;
     st = partition_batch(t, reinterpret_cast<const char*>(dk), 8, reinterpret_cast<const char*>(dv), 4, t->ins.mode == INS_PLUS ? 1u : 0u,
                          n, t->ins.fed, t->ins.PB, t->ins.tmp, t->ins.fin + t->ins.fed, R);
@@ -1483,7 +1497,9 @@ kh_status kh_insert_end(kh_table* t, uint64_t* n_inserted) {
         hipLaunchKernelGGL(k_merge_offsets, dim3((uint32_t)((nq1 + 255) / 256)), dim3(256), 0, t->stream, S, nq1, mo);
         S.merged_off = mo;
       }
+      t->batch_nodup = t->ins.nodup;
       st = insert_finish(t, S, n, t->ins.PB, t->ins.cap_u, t->ins.mode, 0, t->ins.tmp, &nn);
+      t->batch_nodup = false;
     }
   }
   if (st == KH_OK) st = do_reserve(t, t->lsize);
