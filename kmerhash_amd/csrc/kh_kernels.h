@@ -2194,10 +2194,19 @@ __global__ void k_shard_count(const uint64_t* __restrict__ keys, uint64_t n, KhS
     // per-lane counts in 16-bit fields of two 64-bit words, reduced over the wave with shuffles: 8 LDS atomics per wave
     // instead of one per key on 8 hot bins
     unsigned long long c0 = 0, c1 = 0;
-    for (uint32_t j = threadIdx.x; j < KH_SHARD_TILE; j += KH_SHARD_THREADS) {
-      const uint64_t i = base + j;
+    // all eight keys of a lane are requested before the first one is hashed (clamped indices: a branch per key makes the
+    // compiler wait for every load in turn)
+    uint64_t key[KH_SHARD_TILE / KH_SHARD_THREADS];
+#pragma unroll
+    for (uint32_t k = 0; k < KH_SHARD_TILE / KH_SHARD_THREADS; ++k) {
+      const uint64_t i = base + threadIdx.x + k * KH_SHARD_THREADS;
+      key[k] = keys[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < KH_SHARD_TILE / KH_SHARD_THREADS; ++k) {
+      const uint64_t i = base + threadIdx.x + k * KH_SHARD_THREADS;
       if (i < n) {
-        const uint32_t r = kh_rank_of<HASH>(keys[i], seed, p, pmask);
+        const uint32_t r = kh_rank_of<HASH>(key[k], seed, p, pmask);
         if (r < 4) c0 += 1ull << (16 * r); else c1 += 1ull << (16 * (r - 4));
       }
     }
@@ -2274,13 +2283,16 @@ __global__ __launch_bounds__(KH_SHARD_THREADS) void k_shard_scatter8(const uint6
   const uint32_t tile_len = (n - tbase) < KH_SHARD_TILE ? (uint32_t)(n - tbase) : KH_SHARD_TILE;
   uint64_t key[8]; uint32_t val[8]; uint32_t rk[8];
   unsigned long long c0 = 0, c1 = 0;     // counts of ranks 0-3 / 4-7, 16 bits each
+  // (all of a lane's loads first, clamped indices: see k_shard_count)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const uint64_t i = base + j; key[j] = keys[i < n ? i : n - 1]; }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const uint64_t i = base + j; val[j] = vals ? vals[i < n ? i : n - 1] : 0u; }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const uint64_t i = base + j;
     rk[j] = 0xFFu;
     if (i < n) {
-      key[j] = keys[i];
-      val[j] = vals ? vals[i] : 0u;
       rk[j] = kh_rank_of<HASH>(key[j], seed, p, pmask);
       if (rk[j] < 4) c0 += 1ull << (16 * rk[j]); else c1 += 1ull << (16 * (rk[j] - 4));
     }
@@ -2409,7 +2421,13 @@ __global__ __launch_bounds__(256) void k_newline_tile_sums(const uint8_t* __rest
   __shared__ uint32_t wsum[4];
   const uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE + (uint64_t)threadIdx.x * 8;
   uint32_t c = 0;
-  for (int j = 0; j < 8; ++j) if (base + j < n && text[base + j] == '\n') ++c;
+  if (base + 8 <= n && (reinterpret_cast<uintptr_t>(text) & 7u) == 0) {      // one 8-byte load instead of eight dependent byte loads
+    const uint64_t w = *reinterpret_cast<const uint64_t*>(text + base);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c += ((w >> (8 * j)) & 0xFFu) == (uint64_t)'\n' ? 1u : 0u;
+  } else {
+    for (int j = 0; j < 8; ++j) if (base + j < n && text[base + j] == '\n') ++c;
+  }
   for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -2422,8 +2440,16 @@ __global__ __launch_bounds__(256) void k_fastq_mask(const uint8_t* __restrict__ 
   const uint64_t base = (uint64_t)blockIdx.x * KH_CMP_TILE + (uint64_t)tid * 8;
   uint8_t c[8];
   uint32_t mine = 0;
+  if (base + 8 <= n && (reinterpret_cast<uintptr_t>(text) & 7u) == 0) {
+    const uint64_t w = *reinterpret_cast<const uint64_t*>(text + base);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { c[j] = base + j < n ? text[base + j] : (uint8_t)0; mine += c[j] == '\n' ? 1u : 0u; }
+    for (int j = 0; j < 8; ++j) c[j] = (uint8_t)(w >> (8 * j));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = base + j < n ? text[base + j] : (uint8_t)0;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) mine += c[j] == '\n' ? 1u : 0u;
   uint32_t incl = mine;
   for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += o; }
   if (lane == 63) wtot[wid] = incl;
