@@ -23,8 +23,10 @@
 #define KH_L (1u << KH_LB)       // chunk slots (home buckets per workgroup)
 #define KH_HS 4096u              // LDS de-dup set entries per workgroup (16 B each)
 #define KH_CHUNK_THREADS 512
+#ifndef KH_PART_THREADS             // (overridable for experiments: -DKH_PART_THREADS=1024 -DKH_PART_MAXPER=2)
 #define KH_PART_THREADS 512
 #define KH_PART_MAXPER 4            // digits per lane in the scatter's scan: nb <= 2048 bins
+#endif
 #define KH_PART_ITEMS 16
 #define KH_PART_TILE (KH_PART_THREADS * KH_PART_ITEMS)   // 8192 records per partition tile: ONE reservation per (tile, digit)
 #define KH_PART_STAGE 4096       // records staged in LDS at a time: the tile is streamed out in TILE/STAGE rounds
