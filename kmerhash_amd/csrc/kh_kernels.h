@@ -2387,30 +2387,107 @@ __device__ __forceinline__ uint32_t kh_dna_code(uint32_t c) {
   c &= 0xDFu;
   return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
 }
-template <bool CANON>
-__global__ void k_kmers(const uint8_t* __restrict__ seq, uint64_t n, uint32_t k, uint64_t* __restrict__ kmers, uint8_t* __restrict__ flags) {
-  const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * KH_KMER_STRIP;
-  if (p0 >= n) return;
-  const uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
-  uint64_t fw = 0, rc = 0;
-  uint32_t run = 0;
-  for (uint32_t j = 0; j < KH_KMER_STRIP + k - 1; ++j) {
-    const uint64_t pos = p0 + j;
-    if (pos >= n) break;
-    const uint32_t code = kh_dna_code(seq[pos]);
-    if (code > 3u) run = 0;
-    else {
-      fw = ((fw << 2) | code) & mask;
-      rc = (rc >> 2) | ((uint64_t)(3u - code) << (2 * (k - 1)));
-      ++run;
+// Tile of 4096 start positions per 256-lane workgroup.  A lane packs ITS 16 bases (one 16-byte load, coalesced) into a 32-bit word
+// (2 bits per base, first base in the top bits) plus a 16-bit mask of the bytes that are no base; the words go to LDS.  The 16
+// windows that start in a lane's word are then cut out of three consecutive words with funnel shifts: no byte-wise rolling loop,
+// no strided global access.  (The first version read the text one byte at a time at a stride of 64 bytes between lanes and
+// wrote 8-byte k-mers at a stride of 512: 47 GB/s.)  Two passes over the text: count the valid windows per tile, scan, then
+// emit them compacted and in order (staged in LDS, written coalesced) -- the full-size k-mer / flag arrays are gone.
+#define KH_KM_TILE 4096
+#define KH_KM_THREADS 256
+struct KhKmerWin { uint64_t a; uint64_t lo; uint64_t inv; };     // bases 0..31 | bases 32..47 in the top half | 48 invalid bits (base b at bit 47 - b)
+__device__ __forceinline__ void kh_km_pack_tile(const uint8_t* __restrict__ seq, uint64_t n, uint64_t tile0, uint32_t* words, uint16_t* invs) {
+  const uint32_t tid = threadIdx.x;
+  // lanes 0..255 pack the tile's words, lanes 0..1 also the two halo words behind it
+  for (uint32_t w = tid; w < KH_KM_TILE / 16 + 2; w += KH_KM_THREADS) {
+    const uint64_t p0 = tile0 + (uint64_t)w * 16;
+    uint8_t b[16];
+    if (p0 + 16 <= n && ((reinterpret_cast<uintptr_t>(seq) + p0) & 15u) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4*>(seq + p0);
+      const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 16; ++q) b[q] = (uint8_t)(vv[q >> 2] >> (8 * (q & 3)));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) b[q] = p0 + q < n ? seq[p0 + q] : (uint8_t)'\n';
     }
-    if (j >= k - 1) {
-      const uint64_t start = pos - (k - 1);
-      const bool ok = run >= k;
-      flags[start] = ok ? 1 : 0;
-      if (ok) kmers[start] = CANON ? (fw < rc ? fw : rc) : fw;
+    uint32_t word = 0, inv = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const uint32_t c = kh_dna_code(b[q]);
+      word = (word << 2) | (c & 3u);
+      inv = (inv << 1) | (c > 3u ? 1u : 0u);
+    }
+    words[w] = word; invs[w] = (uint16_t)inv;
+  }
+}
+__device__ __forceinline__ KhKmerWin kh_km_window(const uint32_t* words, const uint16_t* invs, uint32_t t) {
+  KhKmerWin W;
+  W.a = ((uint64_t)words[t] << 32) | words[t + 1];
+  W.lo = (uint64_t)words[t + 2] << 32;
+  W.inv = ((uint64_t)invs[t] << 32) | ((uint64_t)invs[t + 1] << 16) | invs[t + 2];
+  return W;
+}
+// the window that starts at base j (0..15) of the lane's word: valid iff none of its k bytes is a non-base
+__device__ __forceinline__ bool kh_km_valid(const KhKmerWin& W, uint32_t j, uint32_t k) {
+  const uint64_t kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+  return ((W.inv >> (48u - j - k)) & kmask) == 0;
+}
+__device__ __forceinline__ uint64_t kh_km_forward(const KhKmerWin& W, uint32_t j, uint32_t k) {
+  const uint64_t x = j ? ((W.a << (2 * j)) | (W.lo >> (64 - 2 * j))) : W.a;       // bases j.. left-aligned
+  return x >> (64 - 2 * k);
+}
+__global__ __launch_bounds__(KH_KM_THREADS) void k_kmers_count(const uint8_t* __restrict__ seq, uint64_t n, uint32_t k, uint32_t* __restrict__ sums) {
+  __shared__ uint32_t words[KH_KM_TILE / 16 + 2];
+  __shared__ uint16_t invs[KH_KM_TILE / 16 + 2];
+  __shared__ uint32_t wsum[KH_KM_THREADS / 64];
+  const uint64_t tile0 = (uint64_t)blockIdx.x * KH_KM_TILE;
+  kh_km_pack_tile(seq, n, tile0, words, invs);
+  __syncthreads();
+  const KhKmerWin W = kh_km_window(words, invs, threadIdx.x);
+  uint32_t c = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 16; ++j) c += kh_km_valid(W, j, k) ? 1u : 0u;      // (bytes behind the text's end were packed as non-bases)
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+template <bool CANON>
+__global__ __launch_bounds__(KH_KM_THREADS) void k_kmers_emit(const uint8_t* __restrict__ seq, uint64_t n, uint32_t k, const uint64_t* __restrict__ tile_off,
+                                                              uint64_t* __restrict__ out) {
+  __shared__ uint32_t words[KH_KM_TILE / 16 + 2];
+  __shared__ uint16_t invs[KH_KM_TILE / 16 + 2];
+  __shared__ uint32_t wtot[KH_KM_THREADS / 64];
+  __shared__ uint64_t stage[KH_KM_TILE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint64_t tile0 = (uint64_t)blockIdx.x * KH_KM_TILE;
+  kh_km_pack_tile(seq, n, tile0, words, invs);
+  __syncthreads();
+  const KhKmerWin W = kh_km_window(words, invs, tid);
+  uint32_t vmask = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 16; ++j) vmask |= kh_km_valid(W, j, k) ? (1u << j) : 0u;
+  const uint32_t mine = (uint32_t)__popc(vmask);
+  uint32_t incl = mine;
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += o; }
+  if (lane == 63) wtot[wid] = incl;
+  __syncthreads();
+  uint32_t pos = incl - mine, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < KH_KM_THREADS / 64; ++w) { const uint32_t c = wtot[w]; if (w < wid) pos += c; total += c; }
+#pragma unroll
+  for (uint32_t j = 0; j < 16; ++j) {
+    if ((vmask >> j) & 1u) {
+      const uint64_t fw = kh_km_forward(W, j, k);
+      uint64_t v = fw;
+      if (CANON) { const uint64_t rc = kh_revcomp(fw, k); v = fw < rc ? fw : rc; }
+      stage[pos++] = v;
     }
   }
+  __syncthreads();
+  const uint64_t o = tile_off[blockIdx.x];
+  for (uint32_t i = tid; i < total; i += KH_KM_THREADS) out[o + i] = stage[i];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1749,26 +1749,24 @@ kh_status kmers_impl(const void* seq, uint64_t n, uint32_t k, int canonical, kh_
   if (!seq || !out_kmers) return KH_ERR_INVALID;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   HIPCHK(hipSetDevice(device));
-  const uint64_t ntl = (n + KH_CMP_TILE - 1) / KH_CMP_TILE;
-  // one pooled block: [text copy (host input)] [masked text (FASTQ)] [all k-mers 8n] [flags n] [tile sums] [tile offsets] [compacted out (host output)]
+  const uint64_t ntl = (n + KH_CMP_TILE - 1) / KH_CMP_TILE;            // tiles of the FASTQ line kernels
+  const uint64_t nkt = (n + KH_KM_TILE - 1) / KH_KM_TILE;              // tiles of the k-mer kernels
+  // one pooled block: [text copy (host input)] [masked text (FASTQ)] [tile sums] [tile offsets] [compacted out (host output)]
   const size_t sz_seq = where == KH_MEM_HOST ? ((n + 255) & ~size_t(255)) : 0;
   const size_t sz_msk = fastq ? ((n + 255) & ~size_t(255)) : 0;
-  const size_t sz_km = n * 8, sz_fl = (n + 255) & ~size_t(255), sz_sum = ((ntl * 4 + 255) & ~size_t(255)), sz_off = (ntl + 1) * 8;
+  const size_t sz_sum = ((ntl * 4 + 255) & ~size_t(255)), sz_off = (ntl + 1) * 8;
   const size_t sz_out = where == KH_MEM_HOST ? n * 8 : 0;
   char* blk = nullptr;
-  HIPCHK(pool_alloc(device, sz_seq + sz_msk + sz_km + sz_fl + sz_sum + sz_off + 256 + sz_out, reinterpret_cast<void**>(&blk)));
+  HIPCHK(pool_alloc(device, sz_seq + sz_msk + sz_sum + sz_off + 256 + sz_out, reinterpret_cast<void**>(&blk)));
   const uint8_t* dseq = static_cast<const uint8_t*>(seq);
   char* p = blk;
   if (where == KH_MEM_HOST) { dseq = reinterpret_cast<uint8_t*>(p); p += sz_seq; }
   uint8_t* msk = reinterpret_cast<uint8_t*>(p); p += sz_msk;
-  uint64_t* km = reinterpret_cast<uint64_t*>(p); p += sz_km;
-  uint8_t* fl = reinterpret_cast<uint8_t*>(p); p += sz_fl;
   uint32_t* sums = reinterpret_cast<uint32_t*>(p); p += sz_sum;
   uint64_t* offs = reinterpret_cast<uint64_t*>(p); p += (sz_off + 255) & ~size_t(255);
   uint64_t* dout = where == KH_MEM_HOST ? reinterpret_cast<uint64_t*>(p) : out_kmers;
   hipError_t e = hipSuccess;
   if (where == KH_MEM_HOST) e = hipMemcpyAsync(const_cast<uint8_t*>(dseq), seq, n, hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(fl, 0, sz_fl, stream);
   if (e == hipSuccess) {
     if (fastq) {      // keep the sequence lines only (line number = newlines before the byte; sequence lines are 1 mod 4)
       hipLaunchKernelGGL(k_newline_tile_sums, dim3((uint32_t)ntl), dim3(256), 0, stream, dseq, n, sums);
@@ -1776,17 +1774,15 @@ kh_status kmers_impl(const void* seq, uint64_t n, uint32_t k, int canonical, kh_
       hipLaunchKernelGGL(k_fastq_mask, dim3((uint32_t)ntl), dim3(256), 0, stream, dseq, n, offs, msk);
       dseq = msk;
     }
-    const uint64_t strips = (n + KH_KMER_STRIP - 1) / KH_KMER_STRIP;
-    const uint32_t grid = (uint32_t)((strips + 255) / 256);
-    if (canonical) hipLaunchKernelGGL((k_kmers<true>), dim3(grid), dim3(256), 0, stream, dseq, n, k, km, fl);
-    else hipLaunchKernelGGL((k_kmers<false>), dim3(grid), dim3(256), 0, stream, dseq, n, k, km, fl);
-    hipLaunchKernelGGL(k_flag_tile_sums, dim3((uint32_t)ntl), dim3(256), 0, stream, fl, n, sums);
-    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, stream, sums, ntl, offs);
-    hipLaunchKernelGGL(k_compact_hits, dim3((uint32_t)ntl), dim3(256), 0, stream, fl, km, (const uint32_t*)nullptr, n, offs, dout, (uint32_t*)nullptr, (uint8_t*)nullptr);
+    // two passes over the text: valid windows per tile, scan, then the windows themselves, compacted and in order
+    hipLaunchKernelGGL(k_kmers_count, dim3((uint32_t)nkt), dim3(KH_KM_THREADS), 0, stream, dseq, n, k, sums);
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, stream, sums, nkt, offs);
+    if (canonical) hipLaunchKernelGGL((k_kmers_emit<true>), dim3((uint32_t)nkt), dim3(KH_KM_THREADS), 0, stream, dseq, n, k, (const uint64_t*)offs, dout);
+    else hipLaunchKernelGGL((k_kmers_emit<false>), dim3((uint32_t)nkt), dim3(KH_KM_THREADS), 0, stream, dseq, n, k, (const uint64_t*)offs, dout);
     e = hipGetLastError();
   }
   uint64_t total = 0;
-  if (e == hipSuccess) e = hipMemcpyAsync(&total, offs + ntl, 8, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, offs + nkt, 8, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e == hipSuccess && where == KH_MEM_HOST && total) {
     e = hipMemcpyAsync(out_kmers, dout, total * 8, hipMemcpyDeviceToHost, stream);
