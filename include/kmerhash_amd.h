@@ -38,7 +38,9 @@ typedef enum {
   KH_ERR_PROBE_OVERFLOW = 4, /* RH probe distance would reach 128: the reference asserts (hashmap_robinhood.hpp:556)
                                 or silently corrupts under -DNDEBUG; we refuse and leave the table unchanged */
   KH_ERR_HIP = 5,            /* a HIP runtime call failed (no GPU, launch failure, ...) */
-  KH_ERR_UNSUPPORTED = 6
+  KH_ERR_UNSUPPORTED = 6,
+  KH_ERR_RETRY = 7           /* kh_insert_end of a KH_INS_REPEATABLE streamed insert: its speculative partition did not hold for this
+                                batch; nothing was inserted; feed the same pieces again after kh_insert_begin without that flag */
 } kh_status;
 
 typedef enum {
@@ -116,6 +118,14 @@ kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n,
  *      kh_insert_feed returns; device buffers must stay valid until the work queued on the table's stream has consumed them
  *      (kh_insert_end synchronises). */
 kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus);
+/* flags: KH_INS_REDUCE_PLUS = kh_insert_begin's reduce_plus.  KH_INS_REPEATABLE: the caller keeps every piece it feeds (valid and
+ *      unchanged) until kh_insert_end has returned and can feed them again.  The library may then partition the pieces without a
+ *      histogram pass into slots they share (and without stream positions when a sample of the first piece shows no duplicate key);
+ *      if that does not hold for the batch -- skewed or duplicated keys -- kh_insert_end returns KH_ERR_RETRY with the table
+ *      unchanged, and the caller repeats begin (without the flag) / feed / end.  (The multi-GPU layer keeps its receive buffers.) */
+#define KH_INS_REDUCE_PLUS 1u
+#define KH_INS_REPEATABLE 2u
+kh_status kh_insert_begin_ex(kh_table* t, uint64_t n_total, unsigned flags);
 kh_status kh_insert_feed(kh_table* t, const void* keys /*[h|d] u64[n]*/, const void* vals /*[h|d] u32[n]*/, uint64_t n, kh_mem where);
 kh_status kh_insert_end(kh_table* t, uint64_t* n_inserted);
 

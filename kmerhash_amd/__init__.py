@@ -4,8 +4,8 @@ The product is libkmerhash_amd.so (hand-written HIP, C-ABI in include/kmerhash_a
 the thin host-side mirror of the reference's interface for Python callers plus workload generators.
 """
 from .table import (hashmap_robinhood_doubling, hashmap_linearprobe_doubling, hash_batch, HASHES,  # noqa: F401
-                    KhError, KhLogicError)
+                    KhError, KhLogicError, KhRetry)
 from . import workloads  # noqa: F401
 
 __all__ = ["hashmap_robinhood_doubling", "hashmap_linearprobe_doubling", "hash_batch", "HASHES", "KhError",
-           "KhLogicError", "workloads"]
+           "KhLogicError", "KhRetry", "workloads"]

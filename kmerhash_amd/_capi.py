@@ -5,20 +5,21 @@ import os
 
 from .build import LIB
 
-KH_OK, KH_ERR_INVALID, KH_ERR_NOMEM, KH_ERR_FULL, KH_ERR_PROBE_OVERFLOW, KH_ERR_HIP, KH_ERR_UNSUPPORTED = range(7)
+KH_OK, KH_ERR_INVALID, KH_ERR_NOMEM, KH_ERR_FULL, KH_ERR_PROBE_OVERFLOW, KH_ERR_HIP, KH_ERR_UNSUPPORTED, KH_ERR_RETRY = range(8)
+KH_INS_REDUCE_PLUS, KH_INS_REPEATABLE = 1, 2
 KH_KIND_ROBINHOOD, KH_KIND_LINEARPROBE = 0, 1
 KH_HASH_IDENTITY, KH_HASH_MURMUR3_X86_128_LO64, KH_HASH_MURMUR3_X64_128_H0, KH_HASH_FARM64 = 0, 1, 2, 3
 KH_MEM_HOST, KH_MEM_DEVICE = 0, 1
 KH_XF_IDENTITY, KH_XF_DNA_LEX_LESS = 0, 1
 
 STATUS_NAMES = {0: "KH_OK", 1: "KH_ERR_INVALID", 2: "KH_ERR_NOMEM", 3: "KH_ERR_FULL", 4: "KH_ERR_PROBE_OVERFLOW",
-                5: "KH_ERR_HIP", 6: "KH_ERR_UNSUPPORTED"}
+                5: "KH_ERR_HIP", 6: "KH_ERR_UNSUPPORTED", 7: "KH_ERR_RETRY"}
 
 # every symbol include/kmerhash_amd.h declares (tests check the library exports each one)
 SYMBOLS = [
     "kh_create", "kh_destroy", "kh_set_stream", "kh_set_key_transform", "kh_get_key_transform", "kh_hash_batch_transformed", "kh_shard_permute_transformed", "kh_last_error", "kh_size", "kh_capacity", "kh_get_load_thresholds",
     "kh_set_min_load_factor", "kh_set_max_load_factor", "kh_get_load_factors", "kh_clear", "kh_reserve", "kh_rehash",
-    "kh_insert", "kh_insert_pairs", "kh_insert_one", "kh_update", "kh_insert_reduce_plus", "kh_insert_begin", "kh_insert_feed", "kh_insert_end", "kh_count", "kh_find", "kh_find_compact", "kh_find_compact_pairs",
+    "kh_insert", "kh_insert_pairs", "kh_insert_one", "kh_update", "kh_insert_reduce_plus", "kh_insert_begin", "kh_insert_begin_ex", "kh_insert_feed", "kh_insert_end", "kh_count", "kh_find", "kh_find_compact", "kh_find_compact_pairs",
     "kh_erase", "kh_erase_one", "kh_to_vector", "kh_export_info", "kh_export_slots", "kh_displacement_histogram",
     "kh_hash_batch", "kh_shard_permute", "kh_profile_enable", "kh_profile_reset", "kh_profile_query", "kh_profile_dump",
     "kh_kmers_from_sequence", "kh_kmers_from_fastq", "kh_hll_create", "kh_hll_destroy", "kh_hll_set_stream", "kh_hll_update", "kh_hll_update_via_hashval",
@@ -34,6 +35,10 @@ class KhError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), msg))
         self.status = status
+
+
+class KhRetry(KhError):
+    """kh_insert_end of a repeatable streamed insert: the speculative partition did not hold; feed the same pieces again"""
 
 
 class KhLogicError(KhError):
@@ -73,6 +78,7 @@ def lib():
     L.kh_update.argtypes = [vp, vp, vp, u64, i32, pu64]
     L.kh_insert_reduce_plus.argtypes = [vp, vp, vp, u64, i32, pu64]
     L.kh_insert_begin.argtypes = [vp, u64, i32]
+    L.kh_insert_begin_ex.argtypes = [vp, u64, u32]
     L.kh_insert_feed.argtypes = [vp, vp, vp, u64, i32]
     L.kh_insert_end.argtypes = [vp, pu64]
     L.kh_count.argtypes = [vp, vp, u64, i32, vp]

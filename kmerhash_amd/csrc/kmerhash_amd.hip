@@ -112,6 +112,9 @@ struct Block { char* p; size_t cap; };
 
 }  // namespace
 
+// histogram-free layout shared by the pieces of a streamed insert: every piece appends to the SAME slots (cursors, overflow flag
+// and the final buffer live across the feeds), so that the build at the end sees one source
+struct SlackShared { unsigned long long* cur2; uint64_t* starts; uint32_t* ovf; uint64_t slot; };
 struct kh_table {
   int kind, hash, device;
   KhSeed seed;      // storage hash seed + key transform (kh_set_key_transform)
@@ -127,6 +130,10 @@ struct kh_table {
   // streamed insert (kh_insert_begin / feed / end)
   struct {
     bool active, fallback, nodup; int mode;       // nodup: a sample of the FIRST feed found no duplicate key (the build then skips its fold, speculatively)
+    // KH_INS_REPEATABLE: the caller can feed the same pieces again, so the speculative forms are allowed: histogram-free partition
+    // into slots shared by all pieces (one source for the build), 12-byte records when the sample found no duplicate
+    bool repeatable, slack, rec12;
+    SlackShared sh;
     uint64_t n_total, fed, cap_u; uint32_t PB;
     ulonglong2 *tmp, *fin;
     KhSrcSet S;
@@ -507,28 +514,34 @@ inline uint64_t part_buffer_records(uint64_t n, uint32_t PB, bool allow_slack) {
 // stream position of the first pair (pairs fed before it in a streamed insert).  Asynchronous on the table's stream.
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
                           uint32_t vconst, uint64_t n, uint64_t idx_base, uint32_t PB, ulonglong2* tmp, ulonglong2* fin, Partitioned& out,
-                          bool allow_slack = false, bool rec12 = false) {
+                          bool allow_slack = false, bool rec12 = false, const SlackShared* shared = nullptr) {
   const uint32_t nparts = 1u << PB;
   out.slot = 0; out.cursor = nullptr; out.overflow = nullptr; out.rec12 = false;
-  if (part_buffer_records(n, PB, allow_slack) != n) {
+  if (shared || part_buffer_records(n, PB, allow_slack) != n) {
     // ---- histogram-free two-pass partition: hashed keys fill the 2^PB partitions evenly, so every partition
     // gets a fixed slot of mean + 7 sigma records and the passes reserve space with their cursors alone: no histogram sweep
     // over the keys (0.33 ms per 1e8), no offset scan.  Level-1 buckets are the unions of their partitions' slots.
     const uint32_t B1 = (PB + 1) / 2, B2 = PB - B1, nb1 = 1u << B1, nb2 = 1u << B2;
-    const uint64_t slot = slack_slot((double)n / (double)nparts), slot1 = slot * nb2;
+    // (a piece of a streamed insert: its level-1 buckets are sized for the piece, the final slots -- shared -- for the whole batch)
+    const uint64_t slot = shared ? shared->slot : slack_slot((double)n / (double)nparts);
+    const uint64_t slot1 = shared ? slack_slot((double)n / (double)nb1) : slot * nb2;
     unsigned long long *cur1, *cur2; uint64_t* starts; uint32_t* ovf; KhTile* tiles; uint32_t* ntiles_dev;
     const uint32_t max_tiles = (uint32_t)(n / KH_PART_TILE) + nb1 + 1;
-    TAKE(cur1, unsigned long long, nb1); TAKE(cur2, unsigned long long, nparts); TAKE(starts, uint64_t, (size_t)nparts + 1); TAKE(ovf, uint32_t, 1);
+    TAKE(cur1, unsigned long long, nb1);
+    if (shared) { cur2 = shared->cur2; starts = shared->starts; ovf = shared->ovf; }
+    else { TAKE(cur2, unsigned long long, nparts); TAKE(starts, uint64_t, (size_t)nparts + 1); TAKE(ovf, uint32_t, 1); }
     TAKE(tiles, KhTile, max_tiles); TAKE(ntiles_dev, uint32_t, 1);
-    HIPCHK(hipMemsetAsync(ovf, 0, 4, t->stream));
     hipLaunchKernelGGL(k_init_cursors, dim3((nb1 + 255) / 256), dim3(256), 0, t->stream, cur1, (uint64_t*)nullptr, (uint64_t)nb1, slot1);
-    hipLaunchKernelGGL(k_init_cursors, dim3((nparts + 256) / 256), dim3(256), 0, t->stream, cur2, starts, (uint64_t)nparts, slot);
+    if (!shared) {
+      HIPCHK(hipMemsetAsync(ovf, 0, 4, t->stream));
+      hipLaunchKernelGGL(k_init_cursors, dim3((nparts + 256) / 256), dim3(256), 0, t->stream, cur2, starts, (uint64_t)nparts, slot);
+    }
     KhPartParams P;
     memset(&P, 0, sizeof(P));
     P.idx_base = idx_base;
     P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.n = n;
     P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
-    P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.cursor = cur1; P.orec = tmp; P.slot = slot1; P.overflow = ovf; P.dump = slot * nparts;
+    P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.cursor = cur1; P.orec = tmp; P.slot = slot1; P.overflow = ovf; P.dump = slot1 * nb1;
     { Launch L(t, "k_part_scatter");
       if (rec12) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, true>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
       else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); } }
@@ -537,7 +550,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     KhPartParams Q = P;
     Q.kbase = nullptr; Q.kstride = 0; Q.vbase = nullptr; Q.vstride = 0; Q.rec_in = tmp;
     Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
-    Q.shift = 0; Q.nb = nb2; Q.cursor = cur2; Q.orec = fin; Q.slot = slot;
+    Q.shift = 0; Q.nb = nb2; Q.cursor = cur2; Q.orec = fin; Q.slot = slot; Q.dump = slot * nparts;
     { Launch L(t, "k_part_scatter");
       if (rec12) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, true>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
       else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); } }
@@ -1409,14 +1422,19 @@ kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n,
 // ---- streamed insert: ONE insert(Iter,Iter) whose input arrives in pieces (the multi-GPU exchange feeds the pieces as
 //      they land; every feed is radix-partitioned right away, asynchronously, so that work overlaps the next transfer)
 kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus) {
+  return kh_insert_begin_ex(t, n_total, reduce_plus ? KH_INS_REDUCE_PLUS : 0u);
+}
+kh_status kh_insert_begin_ex(kh_table* t, uint64_t n_total, unsigned flags) {
   if (!t) return KH_ERR_INVALID;
   if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is already in progress");
+  if (flags & ~(unsigned)(KH_INS_REDUCE_PLUS | KH_INS_REPEATABLE)) return fail(t, KH_ERR_INVALID, "unknown flag");
   HIPCHK(hipSetDevice(t->device));
   memset(&t->ins, 0, sizeof(t->ins));
-  t->ins.mode = reduce_plus ? INS_PLUS : INS_FIRST;
+  t->ins.mode = (flags & KH_INS_REDUCE_PLUS) ? INS_PLUS : INS_FIRST;
+  t->ins.repeatable = (flags & KH_INS_REPEATABLE) != 0 && !g_disable_slack;
   t->ins.n_total = n_total;
   const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n_total ? n_total : 1, n_total, n_total ? n_total - 1 : 0);
-  { kh_status ps = arena_prepare(t, n_total * 56 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 * (KH_MAX_SRC + 1) +
+  { kh_status ps = arena_prepare(t, n_total * ((flags & KH_INS_REPEATABLE) ? 72 : 56) + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 * (KH_MAX_SRC + 1) +
                                     (n_total / KH_PART_TILE + 4096 * KH_MAX_SRC) * 16 + (size_t(8) << 20));
     if (ps != KH_OK) return ps; }
   const uint32_t PB = cu > KH_L ? log2u(cu >> KH_LB) : 0u;
@@ -1426,7 +1444,8 @@ kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus) {
   t->ins.cap_u = cu; t->ins.PB = PB;
   if (n_total) {
     if (t->ins.fallback) { TAKE(t->ins.stage_k, uint64_t, n_total); TAKE(t->ins.stage_v, uint32_t, n_total); }
-    else { TAKE(t->ins.tmp, ulonglong2, n_total); TAKE(t->ins.fin, ulonglong2, n_total); }
+    else if (!t->ins.repeatable) { TAKE(t->ins.tmp, ulonglong2, n_total); TAKE(t->ins.fin, ulonglong2, n_total); }
+    // (repeatable: the first feed's sample decides the layout, the buffers are taken there)
   }
   t->ins.active = true;
   return KH_OK;
@@ -1462,12 +1481,41 @@ kh_status kh_insert_feed(kh_table* t, const void* keys, const void* vals, uint64
       HIPCHK(hipMemcpyAsync(t->hpin + 31, dups, 4, hipMemcpyDeviceToHost, t->stream));
       HIPCHK(hipStreamSynchronize(t->stream));
       t->ins.nodup = (uint32_t)t->hpin[31] == 0u;
+      // a repeatable insert of (nearly) duplicate-free pieces: histogram-free partition into slots all pieces share
+      t->ins.slack = t->ins.repeatable && (uint32_t)t->hpin[31] < 8u && part_buffer_records(t->ins.n_total, t->ins.PB, true) != t->ins.n_total;
+    }
+    if (t->ins.S.n == 0 && t->ins.repeatable) {       // buffers of the chosen layout
+      const uint64_t nt = t->ins.n_total;
+      if (t->ins.slack) {
+        const uint32_t nparts = 1u << t->ins.PB;
+        t->batch_nodup = t->ins.nodup;
+        t->ins.rec12 = nodup_build_applies(t, t->ins.cap_u, t->ins.PB, t->ins.mode);
+        t->batch_nodup = false;
+        SlackShared& sh = t->ins.sh;
+        sh.slot = slack_slot((double)nt / (double)nparts);
+        char* f; TAKE(f, char, (sh.slot * nparts + KH_PART_TILE) * (t->ins.rec12 ? sizeof(KhRec12) : sizeof(ulonglong2)));
+        t->ins.fin = reinterpret_cast<ulonglong2*>(f);
+        TAKE(sh.cur2, unsigned long long, nparts); TAKE(sh.starts, uint64_t, (size_t)nparts + 1); TAKE(sh.ovf, uint32_t, 1);
+        HIPCHK(hipMemsetAsync(sh.ovf, 0, 4, t->stream));
+        hipLaunchKernelGGL(k_init_cursors, dim3((nparts + 256) / 256), dim3(256), 0, t->stream, sh.cur2, sh.starts, (uint64_t)nparts, sh.slot);
+      } else { TAKE(t->ins.tmp, ulonglong2, nt); TAKE(t->ins.fin, ulonglong2, nt); }
     }
     Partitioned R;
-    st = partition_batch(t, reinterpret_cast<const char*>(dk), 8, reinterpret_cast<const char*>(dv), 4, t->ins.mode == INS_PLUS ? 1u : 0u,
-                         n, t->ins.fed, t->ins.PB, t->ins.tmp, t->ins.fin + t->ins.fed, R);
-    if (st != KH_OK) return st;
-    t->ins.S.rec[t->ins.S.n] = R.rec; t->ins.S.off[t->ins.S.n] = R.part_off; ++t->ins.S.n;
+    if (t->ins.slack) {
+      // this piece's level-1 buckets (its own slots), then its records into the shared final slots
+      const uint32_t B1 = (t->ins.PB + 1) / 2, nb1 = 1u << B1;
+      const uint64_t slot1 = slack_slot((double)n / (double)nb1);
+      char* tm; TAKE(tm, char, (slot1 * nb1 + KH_PART_TILE) * (t->ins.rec12 ? sizeof(KhRec12) : sizeof(ulonglong2)));
+      st = partition_batch(t, reinterpret_cast<const char*>(dk), 8, reinterpret_cast<const char*>(dv), 4, t->ins.mode == INS_PLUS ? 1u : 0u,
+                           n, t->ins.fed, t->ins.PB, reinterpret_cast<ulonglong2*>(tm), t->ins.fin, R, true, t->ins.rec12, &t->ins.sh);
+      if (st != KH_OK) return st;
+      t->ins.S.n = 1;      // one source whatever the number of pieces
+    } else {
+      st = partition_batch(t, reinterpret_cast<const char*>(dk), 8, reinterpret_cast<const char*>(dv), 4, t->ins.mode == INS_PLUS ? 1u : 0u,
+                           n, t->ins.fed, t->ins.PB, t->ins.tmp, t->ins.fin + t->ins.fed, R);
+      if (st != KH_OK) return st;
+      t->ins.S.rec[t->ins.S.n] = R.rec; t->ins.S.off[t->ins.S.n] = R.part_off; ++t->ins.S.n;
+    }
   }
   t->ins.fed += n;
   if (where == KH_MEM_HOST) HIPCHK(hipStreamSynchronize(t->stream));   // host buffers may be reused as soon as the feed returns
@@ -1487,6 +1535,23 @@ kh_status kh_insert_end(kh_table* t, uint64_t* n_inserted) {
   if (n) {
     if (t->ins.fallback) {
       st = insert_device(t, reinterpret_cast<const char*>(t->ins.stage_k), 8, reinterpret_cast<const char*>(t->ins.stage_v), 4, n, t->ins.mode, &nn);
+    } else if (t->ins.slack) {
+      const uint32_t nparts = 1u << t->ins.PB;
+      const uint64_t list_cap = t->ins.sh.slot * nparts + KH_PART_TILE;
+      KhSrcSet S;
+      memset(&S, 0, sizeof(S));
+      S.rec[0] = t->ins.fin; S.off[0] = t->ins.sh.starts; S.n = 1; S.merged_off = t->ins.sh.starts;
+      S.slot[0] = t->ins.sh.slot; S.cur[0] = t->ins.sh.cur2; S.rec12 = t->ins.rec12 ? 1u : 0u;
+      char* spare; TAKE(spare, char, list_cap * 16);
+      t->part_overflow = t->ins.sh.ovf; t->batch_nodup = t->ins.nodup;
+      st = insert_finish(t, S, n, t->ins.PB, t->ins.cap_u, t->ins.mode, 0, reinterpret_cast<ulonglong2*>(spare), &nn, list_cap);
+      t->part_overflow = nullptr; t->batch_nodup = false;
+      if (st == KH_RETRY_EXACT) {      // a slot overflowed / a duplicate met without stream positions: nothing was inserted
+        if (n_inserted) *n_inserted = 0;
+        HIPCHK(hipStreamSynchronize(t->stream));
+        t->err = "the speculative partition of this repeatable streamed insert did not hold: feed the same pieces again (kh_insert_begin without KH_INS_REPEATABLE)";
+        return KH_ERR_RETRY;
+      }
     } else {
       KhSrcSet S = t->ins.S;
       if (S.n == 1) S.merged_off = S.off[0];

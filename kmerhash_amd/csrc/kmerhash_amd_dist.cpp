@@ -327,42 +327,54 @@ kh_status khd_insert(khd_map* m, const uint64_t* keys, const uint32_t* vals, uin
   if (!m->tp->exchange_counts(sc.data(), rc.data(), pieces, m->stream, m->err)) return KH_ERR_HIP;
   uint64_t total = 0, max_piece = 0;
   for (int i = 0; i < pieces; ++i) { uint64_t t = 0; for (int s = 0; s < p; ++s) t += rc[(size_t)s * pieces + i]; total += t; max_piece = std::max(max_piece, t); }
-  for (int s = 0; s < 2; ++s)
-    if (!m->rk[s].ensure(std::max<uint64_t>(max_piece, 1) * 8) || (vals && !m->rv[s].ensure(std::max<uint64_t>(max_piece, 1) * 4))) return fail(m, KH_ERR_NOMEM, "receive buffers");
-  KHD_KH(kh_insert_begin(m->local, total, reduce_plus));
-  std::vector<uint64_t> scounts(p), rcounts(p), landed_n(2, 0);
+  // every received piece is KEPT (one buffer for the whole batch, piece after piece) until the build has succeeded: the local
+  // table may then partition the pieces speculatively (KH_INS_REPEATABLE: no histogram pass, slots shared by all pieces) and
+  // ask for them again if that did not hold (KH_ERR_RETRY)
+  (void)max_piece;
+  if (!m->rk[0].ensure(std::max<uint64_t>(total, 1) * 8) || (vals && !m->rv[0].ensure(std::max<uint64_t>(total, 1) * 4))) return fail(m, KH_ERR_NOMEM, "receive buffers");
+  uint64_t* const rk_all = static_cast<uint64_t*>(m->rk[0].p);
+  uint32_t* const rv_all = vals ? static_cast<uint32_t*>(m->rv[0].p) : nullptr;
+  KHD_KH(kh_insert_begin_ex(m->local, total, (reduce_plus ? KH_INS_REDUCE_PLUS : 0u) | KH_INS_REPEATABLE));
+  std::vector<uint64_t> scounts(p), rcounts(p), roff(pieces + 1, 0);
   int landed = -1;
   for (int i = 0; i < pieces; ++i) {
     const int s = i & 1;
-    // send set s was last read by the exchange of piece i-2, receive set s by the feed of piece i-2
+    // send set s was last read by the exchange of piece i-2
     KHD_HIP(hipStreamWaitEvent(m->stream, m->ev_sent[s], 0));
     { Span sp(m, "permute", m->stream);
       kh_status st = permute(m, keys + bounds[i], vals ? vals + bounds[i] : nullptr, bounds[i + 1] - bounds[i], s, scounts.data());
       if (st != KH_OK) return st; }
     uint64_t rtot = 0;
     for (int src = 0; src < p; ++src) { rcounts[src] = rc[(size_t)src * pieces + i]; rtot += rcounts[src]; }
+    roff[i + 1] = roff[i] + rtot;
     KHD_HIP(hipEventRecord(m->ev_perm, m->stream));
     KHD_HIP(hipStreamWaitEvent(m->comm, m->ev_perm, 0));
-    KHD_HIP(hipStreamWaitEvent(m->comm, m->ev_fed[s], 0));
     { Span sp(m, "exchange", m->comm);
-      const void* sb[2] = {m->sk[s].p, m->sv[s].p}; void* rb[2] = {m->rk[s].p, m->rv[s].p}; const int eb[2] = {8, 4};
+      const void* sb[2] = {m->sk[s].p, m->sv[s].p}; void* rb[2] = {rk_all + roff[i], rv_all ? rv_all + roff[i] : nullptr}; const int eb[2] = {8, 4};
       if (!m->tp->exchange(sb, rb, eb, vals ? 2 : 1, scounts.data(), rcounts.data(), m->comm, m->err)) return KH_ERR_HIP; }
     KHD_HIP(hipEventRecord(m->ev_landed[s], m->comm));
     KHD_HIP(hipEventRecord(m->ev_sent[s], m->comm));
     if (landed >= 0) {      // piece i-1 has landed (or is landing): partition it while piece i travels
       KHD_HIP(hipStreamWaitEvent(m->stream, m->ev_landed[landed], 0));
       { Span sp(m, "feed", m->stream);
-        KHD_KH(kh_insert_feed(m->local, m->rk[landed].p, vals ? m->rv[landed].p : nullptr, landed_n[landed], KH_MEM_DEVICE)); }
-      KHD_HIP(hipEventRecord(m->ev_fed[landed], m->stream));
+        KHD_KH(kh_insert_feed(m->local, rk_all + roff[i - 1], rv_all ? rv_all + roff[i - 1] : nullptr, roff[i] - roff[i - 1], KH_MEM_DEVICE)); }
     }
-    landed = s; landed_n[s] = rtot;
+    landed = s;
   }
   KHD_HIP(hipStreamWaitEvent(m->stream, m->ev_landed[landed], 0));
   { Span sp(m, "feed", m->stream);
-    KHD_KH(kh_insert_feed(m->local, m->rk[landed].p, vals ? m->rv[landed].p : nullptr, landed_n[landed], KH_MEM_DEVICE)); }
-  KHD_HIP(hipEventRecord(m->ev_fed[landed], m->stream));
+    KHD_KH(kh_insert_feed(m->local, rk_all + roff[pieces - 1], rv_all ? rv_all + roff[pieces - 1] : nullptr, roff[pieces] - roff[pieces - 1], KH_MEM_DEVICE)); }
+  kh_status est;
   { Span sp(m, "build", m->stream);
-    KHD_KH(kh_insert_end(m->local, n_inserted)); }
+    est = kh_insert_end(m->local, n_inserted); }
+  if (est == KH_ERR_RETRY) {      // the speculative partition did not hold: the kept pieces, concatenated in feed order, the exact way
+    Span sp(m, "refeed", m->stream);
+    KHD_KH(kh_insert_begin(m->local, total, reduce_plus));
+    KHD_KH(kh_insert_feed(m->local, rk_all, rv_all, total, KH_MEM_DEVICE));
+    KHD_KH(kh_insert_end(m->local, n_inserted));
+    return KH_OK;
+  }
+  if (est != KH_OK) return fail(m, est, kh_last_error(m->local));
   return KH_OK;
 }
 

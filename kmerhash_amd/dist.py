@@ -233,7 +233,7 @@ class ShardedTable:
         the comm stream (one grouped launch), and piece i-1 -- already landed -- is radix-partitioned into the local table's
         streamed insert (kh_insert_feed) on the compute stream meanwhile; kh_insert_end de-duplicates and builds once.  xGMI
         transfers and HBM-bound kernels use different resources, so permute + partition hide under the exchange (or the
-        other way round).  Buffers of a piece are released as soon as the piece has been fed.
+        other way round).  The received pieces are kept until the build has succeeded (a repeatable streamed insert, see below).
         Same result as chunks == 1 with the pieces concatenated piece-major (piece, source rank, position)."""
         n = keys.numel()
         if chunks <= 1 or self._single():
@@ -247,7 +247,11 @@ class ShardedTable:
             sc_piece = [self.b.shard_counts(keys[bounds[i]:bounds[i + 1]], self.p) for i in range(chunks)]
         rc = self._exchange_counts([[sc_piece[i][r] for i in range(chunks)] for r in range(self.p)])   # rc[src][piece]
         total = sum(sum(row) for row in rc)
-        self.local.insert_begin(total, reduce_plus=reduce_plus)
+        # the received pieces are kept until the build has succeeded ("repeatable"): the local table may then partition them without
+        # a histogram pass into slots the pieces share; if that speculation fails (skewed / duplicated keys: KhRetry) the kept
+        # pieces are fed again the exact way
+        kept = []
+        self.local.insert_begin(total, reduce_plus=reduce_plus, repeatable=True)
         cur = comm = None
         if cuda:
             cur = torch.cuda.current_stream(self.b.torch_device)
@@ -283,14 +287,25 @@ class ShardedTable:
                     cur.wait_event(landed[0])
                 with self._span("feed"):
                     self.local.insert_feed(landed[1], landed[2])
+                kept.append((landed[1], landed[2]))
             landed = (ev, rk, rv)
             del ok, ov, rk, rv
         if cuda:
             cur.wait_event(landed[0])
         with self._span("feed"):
             self.local.insert_feed(landed[1], landed[2])
+        kept.append((landed[1], landed[2]))
         landed = None
         with self._span("build"):
+            try:
+                return self.local.insert_end()
+            except Exception as ex:
+                if type(ex).__name__ != "KhRetry":
+                    raise
+        with self._span("refeed"):
+            self.local.insert_begin(total, reduce_plus=reduce_plus)
+            for rk, rv in kept:
+                self.local.insert_feed(rk, rv)
             return self.local.insert_end()
 
     def count(self, keys):

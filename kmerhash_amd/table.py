@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _capi as K
 from ._capi import (KH_HASH_FARM64, KH_HASH_IDENTITY, KH_HASH_MURMUR3_X64_128_H0, KH_HASH_MURMUR3_X86_128_LO64,
-                    KH_KIND_LINEARPROBE, KH_KIND_ROBINHOOD, KhError, KhLogicError)
+                    KH_KIND_LINEARPROBE, KH_KIND_ROBINHOOD, KhError, KhLogicError, KhRetry)
 
 try:  # torch is optional for host-array use
     import torch
@@ -86,6 +86,8 @@ class _HashMapBase:
         msg = self._L.kh_last_error(self._h).decode()
         if st == K.KH_ERR_FULL:
             raise KhLogicError(st, msg)
+        if st == K.KH_ERR_RETRY:
+            raise KhRetry(st, msg)
         raise KhError(st, msg)
 
     def _sync_stream(self, *bufs):
@@ -203,8 +205,11 @@ class _HashMapBase:
         return out.value
 
     # -- streamed insert: one insert whose pairs arrive in pieces (multi-GPU exchange) ----------------------------
-    def insert_begin(self, n_total, reduce_plus=False):
-        self._chk(self._L.kh_insert_begin(self._h, int(n_total), 1 if reduce_plus else 0))
+    def insert_begin(self, n_total, reduce_plus=False, repeatable=False):
+        """repeatable: the caller keeps every piece until insert_end has returned and feeds them again (without this flag) if
+        insert_end raises KhRetry -- allows the histogram-free partition of the pieces (kh_insert_begin_ex)"""
+        flags = (K.KH_INS_REDUCE_PLUS if reduce_plus else 0) | (K.KH_INS_REPEATABLE if repeatable else 0)
+        self._chk(self._L.kh_insert_begin_ex(self._h, int(n_total), flags))
 
     def insert_feed(self, keys, vals=None):
         """partition this piece now (asynchronous for device tensors); the pieces count as one batch in feed order"""

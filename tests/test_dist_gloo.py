@@ -46,13 +46,21 @@ class OracleBackend:
                 return new
 
             # streamed insert (kh_insert_begin / feed / end): ONE insert of the concatenated pieces, in feed order
-            def insert_begin(s, n_total, reduce_plus=False):
-                s._feed, s._total, s._plus = [], n_total, reduce_plus
+            def insert_begin(s, n_total, reduce_plus=False, repeatable=False):
+                s._feed, s._total, s._plus, s._rep = [], n_total, reduce_plus, repeatable
 
             def insert_feed(s, k, v=None):
                 s._feed.append((k.clone(), v.clone() if v is not None else None))
 
             def insert_end(s):
+                # force_retry: this repeatable streamed insert "fails its speculation" (like kh_insert_end returning KH_ERR_RETRY):
+                # the sharded layer must feed the pieces it kept again, without the flag
+                if s._rep and getattr(s, "force_retry", False):
+                    class KhRetry(RuntimeError):
+                        pass
+                    s.force_retry = False
+                    s._feed = []
+                    raise KhRetry("speculative partition did not hold")
                 k = torch.cat([a for a, _ in s._feed])
                 assert k.numel() == s._total
                 if s._plus:
@@ -168,6 +176,14 @@ def _worker(rank, world, port, q):
         assert np.array_equal(lp.export_info(), model_p.export_info())
         a, b = lp.sorted_items(), model_p.sorted_items()
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        # the same with a local table whose speculative partition "fails" (KhRetry from insert_end): the kept pieces are fed again
+        sr = ShardedTable(OracleBackend(O, O.KIND_RH), timing=True)
+        sr.local.force_retry = True
+        sr.insert(tk, tv, chunks=chunks)
+        assert "refeed" in sr.timings() and not sr.local.force_retry
+        lr = sr.local.t
+        assert (lr.size(), lr.capacity()) == (model_p.size(), model_p.capacity())
+        assert np.array_equal(lr.export_info(), model_p.export_info())
         # counting insert (Reducer = std::plus): global multiplicities, each k-mer on its owner rank
         sc = ShardedTable(OracleBackend(O, O.KIND_RH))
         sc.insert_counts(tk)

@@ -703,6 +703,65 @@ def test_tiny_and_odd_initial_capacities(oracle, kname, cls, kind, cap0):
 
 
 @pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_repeatable_streamed_insert_partitions_without_a_histogram(oracle, kname, cls, kind):
+    """kh_insert_begin_ex(KH_INS_REPEATABLE): the caller keeps its pieces, so the pieces of a duplicate-free batch are partitioned
+    without a histogram pass into slots they SHARE (one source for the build; 12-byte records).  Hidden duplicates / skew make
+    kh_insert_end return KH_ERR_RETRY with the table unchanged; feeding the same pieces again the plain way gives the reference's
+    result.  A duplicate-heavy first piece takes the exact layout from the start (no retry)."""
+    n = 4_000_000
+    keys = W.distinct_u64(n, seed=77); vals = np.arange(n, dtype=np.uint32)
+    cuts = [0, 900_000, 2_100_000, 3_000_001, n]
+
+    def feed_all(g, k, v, **kw):
+        g.insert_begin(len(k), **kw)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            g.insert_feed(dev(k[a:b]), dev(v[a:b]) if v is not None else None)
+        return g.insert_end()
+
+    # 1. distinct keys: speculative layout holds
+    g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    g.profile_enable(True)
+    assert feed_all(g, keys, vals, repeatable=True) == o.insert(keys, vals)
+    p = g.profile()
+    assert "k_part_hist" not in p and p["k_part_scatter"][0] == 2 * (len(cuts) - 1) and "k_dedup" not in p, p
+    check_state(g, o, kind)
+    g.close()
+    # 2. duplicates the first piece's sample cannot see (in the LAST piece): KhRetry, nothing inserted, then the plain way
+    k2 = keys.copy()
+    k2[3_500_000:3_500_300] = keys[10:310]
+    g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    with pytest.raises(kh.KhRetry):
+        feed_all(g, k2, vals, repeatable=True)
+    assert g.size() == 0
+    assert feed_all(g, k2, vals) == o.insert(k2, vals)
+    check_state(g, o, kind)
+    g.close()
+    # 3. one key 40000 times in a later piece: a slot overflows -> KhRetry as well
+    k3 = keys.copy()
+    k3[2_200_000:2_240_000] = keys[5]
+    g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    with pytest.raises(kh.KhRetry):
+        feed_all(g, k3, vals, repeatable=True)
+    assert feed_all(g, k3, vals) == o.insert(k3, vals)
+    check_state(g, o, kind)
+    g.close()
+    # 4. duplicate-heavy batch: the first piece's sample sees it, exact layout, no retry
+    kd, vd = W.w1_benchmark_hashtables(n, seed=5)
+    g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    g.profile_enable(True)
+    assert feed_all(g, kd, vd, repeatable=True) == o.insert(kd, vd)
+    assert "k_part_hist" in g.profile()
+    check_state(g, o, kind)
+    g.close()
+    # 5. counting form (Reducer = std::plus, values omitted), repeatable, into an empty table
+    g = cls(128, 0.35, 0.8)
+    feed_all(g, keys, None, reduce_plus=True, repeatable=True)
+    sk, sv = g.sorted_items()
+    assert np.array_equal(sk, np.sort(keys)) and (sv == 1).all()
+    g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
 @pytest.mark.parametrize("pieces", [1, 2, 5, 16])
 def test_streamed_insert_equals_one_insert(oracle, kname, cls, kind, pieces):
     """kh_insert_begin/feed/end: the pieces of one batch, each partitioned on arrival, count as ONE insert(Iter,Iter) in
