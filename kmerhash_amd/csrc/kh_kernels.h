@@ -2382,7 +2382,6 @@ __global__ void k_hll_merge(uint32_t* __restrict__ dst, const uint32_t* __restri
 // base in the most significant position (bliss::common::Kmer::nextFromChar order), A=0 C=1 G=2 T=3; any other byte
 // (newline, N, ...) breaks the run.  CANON: min(k-mer, reverse complement).  One lane rolls over 64 start positions.
 // ---------------------------------------------------------------------------------------------
-#define KH_KMER_STRIP 64
 __device__ __forceinline__ uint32_t kh_dna_code(uint32_t c) {
   c &= 0xDFu;
   return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
