@@ -182,6 +182,19 @@ kh_status kh_shard_permute_transformed(kh_hash hash, uint64_t seed, kh_key_trans
                                        const uint64_t* keys_dev, const uint32_t* vals_dev, uint64_t n,
                                        uint64_t* out_keys_dev, uint32_t* out_vals_dev, uint64_t* counts_host, int device, void* hip_stream);
 
+/* ---- a batch that will be exchanged in `pieces` pieces (the pipelined insert): ONE count sweep + scan + host synchronisation for the
+ *      whole batch.  bounds_host[pieces+1] receives the piece boundaries (multiples of 4096 pairs, the last one = n),
+ *      counts_host[pieces][nranks] the destination counts of every piece; kh_shard_plan_permute then permutes piece i (pairs
+ *      [bounds[i], bounds[i+1]) of the SAME keys/vals arrays, unchanged since the plan was made) into out_* grouped by rank, input
+ *      order kept, without counting again and without synchronising.  nranks <= 8.  Same result as kh_shard_permute on the piece. */
+typedef struct kh_shard_plan kh_shard_plan;
+kh_status kh_shard_plan_create(kh_shard_plan** out, kh_hash hash, uint64_t seed, kh_key_transform xf, uint32_t k, uint32_t nranks,
+                               const uint64_t* keys_dev, uint64_t n, uint32_t pieces, uint64_t* counts_host, uint64_t* bounds_host,
+                               int device, void* hip_stream);
+kh_status kh_shard_plan_permute(kh_shard_plan* plan, uint32_t piece, const uint64_t* keys_dev, const uint32_t* vals_dev /* may be NULL */,
+                                uint64_t* out_keys_dev, uint32_t* out_vals_dev, void* hip_stream);
+void kh_shard_plan_destroy(kh_shard_plan* plan);
+
 /* ---- k-mer generation front end (BenchmarkKmerCounter.cpp:1655-1706 reads sequences through kmerind's
  *      KmerParser, which is not part of the reference tree: PARITY UNPINNED, the definition below is this library's):
  *      every window of k valid bases (ACGT, either case) of `seq` yields one 2-bit packed k-mer (first base most

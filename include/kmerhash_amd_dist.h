@@ -53,7 +53,9 @@ int khd_nranks(const khd_map* m);
 
 /* insert_p (:910-1194).  vals == NULL with reduce_plus != 0: counting insert (std::plus, 1 per occurrence;
  * counting_batched_robinhood_map::insert :2542-2950).  pieces > 1: the batch is cut into `pieces` parts whose exchange overlaps the
- * radix partition of the part before (at most 16); same result as pieces == 1 with the parts concatenated piece-major. */
+ * radix partition of the part before (at most 16); same result as pieces == 1 with the parts concatenated piece-major.  Up to 8
+ * ranks the parts are cut at multiples of 4096 pairs (part i = pairs [4096 * (T * i / pieces), 4096 * (T * (i + 1) / pieces)),
+ * T = ceil(n / 4096): kh_shard_plan), otherwise at n * i / pieces. */
 kh_status khd_insert(khd_map* m, const uint64_t* keys_dev, const uint32_t* vals_dev, uint64_t n, int pieces, int reduce_plus,
                      uint64_t* n_inserted_local);
 /* count_p (:1258): out_keys_dev[n] = the keys grouped by owner rank, out01_dev[n] = 0/1 aligned with them */

@@ -2180,6 +2180,14 @@ __global__ void k_unpack_slots(const KhSlot* __restrict__ slots, uint64_t cap, u
 #define KH_SHARD_THREADS 512
 #define KH_SHARD_TILE (KH_SHARD_THREADS * 8)     // 8 consecutive items per lane; fewer, larger tiles keep the [rank][tile] offset scan short
 #define KH_SHARD_MAXR 64
+struct KhShardAdj { long long a[8]; __host__ __device__ KhShardAdj() { for (int i = 0; i < 8; ++i) a[i] = 0; } };
+// entries (r, i) -> tile_off[r * ntiles + ntiles * i / pieces] for r <= p... (the offsets at the piece boundaries of a kh_shard_plan)
+__global__ void k_shard_piece_bounds(const uint64_t* __restrict__ tile_off, uint32_t ntiles, uint32_t p, uint32_t pieces, uint64_t* __restrict__ out /* [p][pieces+1] */) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= p * (pieces + 1)) return;
+  const uint32_t r = j / (pieces + 1), i = j % (pieces + 1);
+  out[j] = tile_off[(uint64_t)r * ntiles + (uint64_t)ntiles * i / pieces];
+}
 template <int HASH>
 __device__ __forceinline__ uint32_t kh_rank_of(uint64_t key, KhSeed seed, uint32_t p, uint32_t pmask) {
   uint64_t h = kh_hash64<HASH>(key, seed);
@@ -2274,7 +2282,10 @@ template <int HASH>
 __global__ __launch_bounds__(KH_SHARD_THREADS) void k_shard_scatter8(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n,
                                                           KhSeed seed, uint32_t p, uint32_t pmask,
                                                           const uint64_t* __restrict__ tile_off /* [p][ntiles] exclusive */,
-                                                          uint32_t ntiles, uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
+                                                          uint32_t ntiles, uint64_t* __restrict__ ok, uint32_t* __restrict__ ov,
+                                                          uint32_t tile0 = 0, KhShardAdj adj = KhShardAdj()) {
+  // (tile0 / adj: the launch covers the tiles [tile0, tile0 + gridDim.x) of a larger batch whose offsets tile_off holds -- one piece
+  //  of a kh_shard_plan; keys / vals / n are the piece's own, adj[r] turns the batch-wide offset of rank r into the piece's)
   __shared__ uint64_t lk[KH_SHARD_TILE];
   __shared__ uint32_t lv[KH_SHARD_TILE];
   __shared__ unsigned long long wtot[KH_SHARD_THREADS / 64][2];
@@ -2335,7 +2346,7 @@ __global__ __launch_bounds__(KH_SHARD_THREADS) void k_shard_scatter8(const uint6
     uint32_t r = 0;
 #pragma unroll
     for (uint32_t k = 1; k < 8; ++k) r += (s >= rank_off[k]) ? 1u : 0u;
-    const uint64_t pos = tile_off[(uint64_t)r * ntiles + blockIdx.x] + (s - rank_off[r]);
+    const uint64_t pos = tile_off[(uint64_t)r * ntiles + tile0 + blockIdx.x] + (uint64_t)adj.a[r] + (s - rank_off[r]);
     ok[pos] = lk[s];
     if (vals) ov[pos] = lv[s];
   }

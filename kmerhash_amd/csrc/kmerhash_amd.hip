@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 
@@ -1799,6 +1800,82 @@ kh_status kh_shard_permute_transformed(kh_hash hash, uint64_t seed_, kh_key_tran
   if (e != hipSuccess) return KH_ERR_HIP;
   for (uint32_t r = 0; r < p; ++r) counts_host[r] = ends[r + 1] - ends[r];
   return KH_OK;
+}
+
+// ---- shard plan: ONE count sweep + scan over a whole batch that is going to be exchanged in pieces; the per-piece destination
+//      counts fall out of the scanned offsets at the piece boundaries (tile-aligned), and every piece is then permuted by the
+//      scatter kernel alone (no second count, no second scan, one host synchronisation instead of one per piece)
+struct kh_shard_plan {
+  int device, hash; KhSeed seed; uint32_t p, pmask, pieces, ntiles; uint64_t n;
+  uint32_t* tc; uint64_t* toff; uint64_t* bnd_dev;
+  std::vector<uint64_t> bnd;      // [p][pieces+1] scanned offsets at the piece boundaries
+};
+kh_status kh_shard_plan_create(kh_shard_plan** out, kh_hash hash, uint64_t seed_, kh_key_transform xf, uint32_t k, uint32_t p, const uint64_t* keys,
+                               uint64_t n, uint32_t pieces, uint64_t* counts_host, uint64_t* bounds_host, int device, void* stream_) {
+  kh_table* t = nullptr;
+  if (!out) return KH_ERR_INVALID;
+  *out = nullptr;
+  if (p == 0 || p > 8 || pieces == 0 || pieces > 64 || !counts_host || !bounds_host || (int)hash < 0 || (int)hash > 3 || !xform_ok(xf, k) || (n && !keys)) return KH_ERR_INVALID;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(device));
+  std::unique_ptr<kh_shard_plan> P(new kh_shard_plan());
+  P->device = device; P->hash = (int)hash; P->seed = make_seed(seed_, xf, k); P->p = p; P->pmask = (p & (p - 1)) == 0 ? p - 1 : 0;
+  P->pieces = pieces; P->n = n; P->tc = nullptr; P->toff = nullptr; P->bnd_dev = nullptr;
+  P->ntiles = (uint32_t)((n + KH_SHARD_TILE - 1) / KH_SHARD_TILE);
+  for (uint32_t i = 0; i <= pieces; ++i) bounds_host[i] = std::min<uint64_t>(n, ((uint64_t)P->ntiles * i / pieces) * KH_SHARD_TILE);
+  for (uint64_t j = 0; j < (uint64_t)pieces * p; ++j) counts_host[j] = 0;
+  P->bnd.assign((size_t)p * (pieces + 1), 0);
+  if (n) {
+    const uint64_t m = (uint64_t)p * P->ntiles;
+    HIPCHK(pool_alloc(device, m * 4, reinterpret_cast<void**>(&P->tc)));
+    if (pool_alloc(device, (m + 1) * 8, reinterpret_cast<void**>(&P->toff)) != hipSuccess ||
+        pool_alloc(device, P->bnd.size() * 8, reinterpret_cast<void**>(&P->bnd_dev)) != hipSuccess) {
+      if (P->toff) pool_free(device, P->toff);
+      pool_free(device, P->tc);
+      return KH_ERR_NOMEM;
+    }
+    KH_SWITCH_HASH((int)hash, hipLaunchKernelGGL((k_shard_count<HASH>), dim3(P->ntiles), dim3(KH_SHARD_THREADS), 0, stream, keys, n, P->seed, p, P->pmask, P->tc, P->ntiles));
+    hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, stream, P->tc, m, P->toff);
+    hipLaunchKernelGGL(k_shard_piece_bounds, dim3(1 + (uint32_t)P->bnd.size() / 256), dim3(256), 0, stream, (const uint64_t*)P->toff, P->ntiles, p, pieces, P->bnd_dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(P->bnd.data(), P->bnd_dev, P->bnd.size() * 8, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { pool_free(device, P->tc); pool_free(device, P->toff); pool_free(device, P->bnd_dev); return KH_ERR_HIP; }
+    for (uint32_t i = 0; i < pieces; ++i)
+      for (uint32_t r = 0; r < p; ++r) counts_host[(size_t)i * p + r] = P->bnd[(size_t)r * (pieces + 1) + i + 1] - P->bnd[(size_t)r * (pieces + 1) + i];
+  }
+  *out = P.release();
+  return KH_OK;
+}
+kh_status kh_shard_plan_permute(kh_shard_plan* P, uint32_t piece, const uint64_t* keys, const uint32_t* vals, uint64_t* out_keys, uint32_t* out_vals,
+                                void* stream_) {
+  kh_table* t = nullptr;
+  if (!P || piece >= P->pieces || (vals && !out_vals)) return KH_ERR_INVALID;
+  if (P->n == 0) return KH_OK;
+  if (!keys || !out_keys) return KH_ERR_INVALID;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(P->device));
+  const uint32_t t0 = (uint32_t)((uint64_t)P->ntiles * piece / P->pieces), t1 = (uint32_t)((uint64_t)P->ntiles * (piece + 1) / P->pieces);
+  if (t1 == t0) return KH_OK;
+  const uint64_t b0 = (uint64_t)t0 * KH_SHARD_TILE, b1 = std::min<uint64_t>(P->n, (uint64_t)t1 * KH_SHARD_TILE);
+  KhShardAdj adj;
+  uint64_t base = 0;      // where rank r's pairs of THIS piece start in the piece's output
+  for (uint32_t r = 0; r < P->p; ++r) {
+    const uint64_t lo = P->bnd[(size_t)r * (P->pieces + 1) + piece], hi = P->bnd[(size_t)r * (P->pieces + 1) + piece + 1];
+    adj.a[r] = (long long)base - (long long)lo;
+    base += hi - lo;
+  }
+  KH_SWITCH_HASH(P->hash, hipLaunchKernelGGL((k_shard_scatter8<HASH>), dim3(t1 - t0), dim3(KH_SHARD_THREADS), 0, stream, keys + b0, vals ? vals + b0 : nullptr, b1 - b0,
+                                             P->seed, P->p, P->pmask, (const uint64_t*)P->toff, P->ntiles, out_keys, out_vals, t0, adj));
+  HIPCHK(hipGetLastError());
+  return KH_OK;
+}
+void kh_shard_plan_destroy(kh_shard_plan* P) {
+  if (!P) return;
+  if (P->tc) pool_free(P->device, P->tc);
+  if (P->toff) pool_free(P->device, P->toff);
+  if (P->bnd_dev) pool_free(P->device, P->bnd_dev);
+  delete P;
 }
 
 // ---- k-mer generation front end ----------------------------------------------------------------------

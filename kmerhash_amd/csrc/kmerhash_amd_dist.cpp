@@ -315,9 +315,19 @@ kh_status khd_insert(khd_map* m, const uint64_t* keys, const uint32_t* vals, uin
   if (pieces < 1) pieces = 1;
   std::vector<uint64_t> bounds(pieces + 1);
   for (int i = 0; i <= pieces; ++i) bounds[i] = n * (uint64_t)i / (uint64_t)pieces;
-  // ---- count-only pass per piece, ONE exchange for all the counts: rc[src * pieces + piece]
+  // ---- destination counts of every piece, ONE exchange for all of them: rc[src * pieces + piece].  Up to 8 ranks: one count sweep +
+  //      scan + host synchronisation for the whole batch (kh_shard_plan; the pieces are then permuted without counting again,
+  //      their boundaries are the plan's: multiples of 4096 pairs); more ranks: a count-only pass per piece
   std::vector<uint64_t> sc((size_t)p * pieces), rc((size_t)p * pieces), tmp(p);
+  struct PlanGuard { kh_shard_plan* h = nullptr; ~PlanGuard() { kh_shard_plan_destroy(h); } } plan;
   { Span sp(m, "count_pass", m->stream);
+    if (p <= 8) {
+      std::vector<uint64_t> pc((size_t)pieces * p);
+      kh_status st = kh_shard_plan_create(&plan.h, m->dist_hash, m->dist_seed, KH_XF_IDENTITY, 0, (uint32_t)p, keys, n, (uint32_t)pieces, pc.data(), bounds.data(),
+                                          m->device, m->stream);
+      if (st != KH_OK) return fail(m, st, "kh_shard_plan_create");
+      for (int i = 0; i < pieces; ++i) for (int d = 0; d < p; ++d) sc[(size_t)d * pieces + i] = pc[(size_t)i * p + d];
+    } else
     for (int i = 0; i < pieces; ++i) {
       kh_status st = kh_shard_permute(m->dist_hash, m->dist_seed, (uint32_t)p, keys + bounds[i], nullptr, bounds[i + 1] - bounds[i], nullptr, nullptr,
                                       tmp.data(), m->device, m->stream);
@@ -342,8 +352,16 @@ kh_status khd_insert(khd_map* m, const uint64_t* keys, const uint32_t* vals, uin
     // send set s was last read by the exchange of piece i-2
     KHD_HIP(hipStreamWaitEvent(m->stream, m->ev_sent[s], 0));
     { Span sp(m, "permute", m->stream);
-      kh_status st = permute(m, keys + bounds[i], vals ? vals + bounds[i] : nullptr, bounds[i + 1] - bounds[i], s, scounts.data());
-      if (st != KH_OK) return st; }
+      if (plan.h) {
+        const uint64_t np_ = bounds[i + 1] - bounds[i];
+        if (!m->sk[s].ensure(std::max<uint64_t>(np_, 1) * 8) || (vals && !m->sv[s].ensure(std::max<uint64_t>(np_, 1) * 4))) return fail(m, KH_ERR_NOMEM, "send buffers");
+        kh_status st = kh_shard_plan_permute(plan.h, (uint32_t)i, keys, vals, static_cast<uint64_t*>(m->sk[s].p), vals ? static_cast<uint32_t*>(m->sv[s].p) : nullptr, m->stream);
+        if (st != KH_OK) return fail(m, st, "kh_shard_plan_permute");
+        for (int d = 0; d < p; ++d) scounts[d] = sc[(size_t)d * pieces + i];
+      } else {
+        kh_status st = permute(m, keys + bounds[i], vals ? vals + bounds[i] : nullptr, bounds[i + 1] - bounds[i], s, scounts.data());
+        if (st != KH_OK) return st;
+      } }
     uint64_t rtot = 0;
     for (int src = 0; src < p; ++src) { rcounts[src] = rc[(size_t)src * pieces + i]; rtot += rcounts[src]; }
     roff[i + 1] = roff[i] + rtot;

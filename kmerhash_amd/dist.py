@@ -80,6 +80,47 @@ class GpuBackend:
     def empty(self, n, dtype):
         return torch.empty(n, dtype=dtype, device=self.torch_device)
 
+    def shard_plan(self, keys, p, pieces):
+        """ONE count sweep + scan + host synchronisation for a batch that travels in `pieces` pieces (kh_shard_plan_create):
+        -> (plan, bounds[pieces+1] (tile-aligned piece boundaries), counts[piece][p]); None when the library cannot plan it"""
+        if p > 8:
+            return None
+        plan = self.C.c_void_p()
+        counts = (self.C.c_uint64 * (p * pieces))()
+        bounds = (self.C.c_uint64 * (pieces + 1))()
+        st = self.K.lib().kh_shard_plan_create(self.C.byref(plan), self.dist_hash, self.dist_seed, 0, 0, p, keys.data_ptr(), keys.numel(), pieces,
+                                               counts, bounds, self.device, torch.cuda.current_stream(self.device).cuda_stream)
+        if st != self.K.KH_OK:
+            raise self.K.KhError(st, "kh_shard_plan_create")
+        return _ShardPlan(self, plan, keys), [int(b) for b in bounds], [[int(counts[i * p + r]) for r in range(p)] for i in range(pieces)]
+
+
+def plan_piece_bounds(n, pieces):
+    """where kh_shard_plan cuts a batch of n pairs into `pieces` pieces: at multiples of 4096 pairs"""
+    nt = (n + 4095) // 4096
+    return [min(n, (nt * i // pieces) * 4096) for i in range(pieces + 1)]
+
+
+class _ShardPlan:
+    def __init__(self, be, handle, keys):
+        self.be, self.h, self.keys = be, handle, keys      # (keeps the key tensor alive: the plan refers to it)
+
+    def permute(self, piece, vals, n_piece):
+        """piece `piece` of the planned batch grouped by destination rank (no second count, no synchronisation)"""
+        be = self.be
+        ok = torch.empty(n_piece, dtype=self.keys.dtype, device=self.keys.device)
+        ov = torch.empty(n_piece, dtype=vals.dtype, device=vals.device) if vals is not None else None
+        st = be.K.lib().kh_shard_plan_permute(self.h, piece, self.keys.data_ptr(), vals.data_ptr() if vals is not None else None, ok.data_ptr(),
+                                              ov.data_ptr() if ov is not None else None, torch.cuda.current_stream(be.device).cuda_stream)
+        if st != be.K.KH_OK:
+            raise be.K.KhError(st, "kh_shard_plan_permute")
+        return ok, ov
+
+    def close(self):
+        if self.h:
+            self.be.K.lib().kh_shard_plan_destroy(self.h)
+            self.h = None
+
 
 class _Phases:
     """per-phase device timings of the sharded operations (HIP events on the stream the phase runs on); off by default"""
@@ -242,9 +283,15 @@ class ShardedTable:
                 return self.local.insert_reduce_plus(rk, rv) if reduce_plus else self.local.insert(rk, rv)
         cuda = keys.is_cuda            # host tensors (CPU test backends): the same piece loop without streams
         bounds = [n * i // chunks for i in range(chunks + 1)]
-        # per-piece destination counts (count-only pass), one exchange for all of them: row = destination rank, column = piece
+        # per-piece destination counts (count-only pass), one exchange for all of them: row = destination rank, column = piece.
+        # GPU backend: one sweep + one synchronisation for all pieces (kh_shard_plan), the pieces are then permuted without recounting
+        plan = None
         with self._span("count_pass"):
-            sc_piece = [self.b.shard_counts(keys[bounds[i]:bounds[i + 1]], self.p) for i in range(chunks)]
+            planned = self.b.shard_plan(keys, self.p, chunks) if hasattr(self.b, "shard_plan") else None
+            if planned is not None:
+                plan, bounds, sc_piece = planned
+            else:
+                sc_piece = [self.b.shard_counts(keys[bounds[i]:bounds[i + 1]], self.p) for i in range(chunks)]
         rc = self._exchange_counts([[sc_piece[i][r] for i in range(chunks)] for r in range(self.p)])   # rc[src][piece]
         total = sum(sum(row) for row in rc)
         # the received pieces are kept until the build has succeeded ("repeatable"): the local table may then partition them without
@@ -262,7 +309,11 @@ class ShardedTable:
         for i in range(chunks):
             a, b = bounds[i], bounds[i + 1]
             with self._span("permute"):
-                ok, ov, scounts = self.b.shard(keys[a:b], vals[a:b] if vals is not None else None, self.p)     # compute stream (stable permutation)
+                if plan is not None:
+                    ok, ov = plan.permute(i, vals, b - a)
+                    scounts = sc_piece[i]
+                else:
+                    ok, ov, scounts = self.b.shard(keys[a:b], vals[a:b] if vals is not None else None, self.p)     # compute stream (stable permutation)
             assert list(scounts) == list(sc_piece[i]), "count-only pass and permutation disagree"
             rcounts = [rc[src][i] for src in range(self.p)]
             ev = None
@@ -302,6 +353,9 @@ class ShardedTable:
             except Exception as ex:
                 if type(ex).__name__ != "KhRetry":
                     raise
+            finally:
+                if plan is not None:      # (insert_end has synchronised: the last piece's permutation no longer reads the plan)
+                    plan.close()
         with self._span("refeed"):
             self.local.insert_begin(total, reduce_plus=reduce_plus)
             for rk, rv in kept:

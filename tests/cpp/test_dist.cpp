@@ -57,7 +57,9 @@ static void local_group(int P, int pieces, size_t n_per_rank) {
     std::vector<uint64_t> ck; std::vector<uint32_t> cv;
     for (int pc = 0; pc < pieces; ++pc)
       for (int r = 0; r < P; ++r) {
-        const size_t a = n_per_rank * pc / pieces, b = n_per_rank * (pc + 1) / pieces;
+        // (piece boundaries of khd_insert for up to 8 ranks: kh_shard_plan's, multiples of 4096 pairs)
+        const size_t nt = (n_per_rank + 4095) / 4096;
+        const size_t a = std::min(n_per_rank, (nt * pc / pieces) * 4096), b = std::min(n_per_rank, (nt * (pc + 1) / pieces) * 4096);
         ck.insert(ck.end(), keys[r].begin() + a, keys[r].begin() + b); cv.insert(cv.end(), vals[r].begin() + a, vals[r].begin() + b);
       }
     uint64_t ni = 0; OK(kh_insert(model, ck.data(), cv.data(), ck.size(), KH_MEM_HOST, &ni));

@@ -32,7 +32,7 @@ def _worker(rank, world, port, q):
     try:
         from oracle import oracle_py as O
         from kmerhash_amd import workloads as W
-        from kmerhash_amd.dist import GpuBackend, ShardedTable, DIST_SEED
+        from kmerhash_amd.dist import GpuBackend, ShardedTable, DIST_SEED, plan_piece_bounds
         torch.cuda.set_device(0)
         n = 400_000
         keys, vals = W.w1_benchmark_hashtables(n, seed=100)
@@ -53,7 +53,7 @@ def _worker(rank, world, port, q):
                     m = owner(allk[r]) == rank
                     model.insert(allk[r][m], allv[r][m])
             else:   # piece i of every rank arrives before piece i+1 of any rank
-                b = [n * i // chunks for i in range(chunks + 1)]
+                b = plan_piece_bounds(n, chunks)          # (GPU backend, <= 8 ranks: the pieces are cut at multiples of 4096 pairs)
                 for i in range(chunks):
                     for r in range(world):
                         kk, vv = allk[r][b[i]:b[i + 1]], allv[r][b[i]:b[i + 1]]

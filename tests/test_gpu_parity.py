@@ -702,6 +702,36 @@ def test_tiny_and_odd_initial_capacities(oracle, kname, cls, kind, cap0):
     g.close()
 
 
+def test_shard_plan_equals_per_piece_permute():
+    """kh_shard_plan: one count sweep for a batch cut into pieces; every piece's permutation and counts equal kh_shard_permute run on
+    that piece alone (stable, same destination ranks)"""
+    import ctypes as C
+    from kmerhash_amd import _capi as K
+    L = K.lib()
+    for n, p, pieces in ((1_000_003, 8, 4), (70_000, 3, 5), (4096, 2, 3), (5, 4, 2)):
+        keys = W.splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(n))
+        keys[::7] = keys[0]                                   # duplicates
+        vals = np.arange(n, dtype=np.uint32)
+        dk, dv = dev(keys), dev(vals)
+        plan = C.c_void_p()
+        counts = (C.c_uint64 * (p * pieces))(); bounds = (C.c_uint64 * (pieces + 1))()
+        assert L.kh_shard_plan_create(C.byref(plan), 1, 9876543, 0, 0, p, dk.data_ptr(), n, pieces, counts, bounds, 0, None) == K.KH_OK
+        b = [int(x) for x in bounds]
+        assert b[0] == 0 and b[-1] == n and all(x % 4096 == 0 for x in b[:-1]) and b == sorted(b)
+        for i in range(pieces):
+            m = b[i + 1] - b[i]
+            ok = torch.empty(max(m, 1), dtype=torch.int64, device="cuda"); ov = torch.empty(max(m, 1), dtype=torch.int32, device="cuda")
+            assert L.kh_shard_plan_permute(plan, i, dk.data_ptr(), dv.data_ptr(), ok.data_ptr(), ov.data_ptr(), None) == K.KH_OK
+            rk = torch.empty(max(m, 1), dtype=torch.int64, device="cuda"); rv = torch.empty(max(m, 1), dtype=torch.int32, device="cuda")
+            rc = (C.c_uint64 * p)()
+            assert L.kh_shard_permute(1, 9876543, p, dk[b[i]:].data_ptr() if m else None, dv[b[i]:].data_ptr() if m else None, m,
+                                      rk.data_ptr(), rv.data_ptr(), rc, 0, None) == K.KH_OK
+            torch.cuda.synchronize()
+            assert [int(counts[i * p + r]) for r in range(p)] == [int(x) for x in rc]
+            assert torch.equal(ok[:m], rk[:m]) and torch.equal(ov[:m], rv[:m])
+        L.kh_shard_plan_destroy(plan)
+
+
 @pytest.mark.parametrize("kname,cls,kind", KINDS)
 def test_repeatable_streamed_insert_partitions_without_a_histogram(oracle, kname, cls, kind):
     """kh_insert_begin_ex(KH_INS_REPEATABLE): the caller keeps its pieces, so the pieces of a duplicate-free batch are partitioned
