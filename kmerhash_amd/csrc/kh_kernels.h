@@ -648,11 +648,19 @@ __device__ __forceinline__ void kh_rec_set(ulonglong2& r, uint64_t key, unsigned
 __device__ __forceinline__ void kh_rec_set(KhRec12& r, uint64_t key, unsigned long long iv) { r.klo = (uint32_t)key; r.khi = (uint32_t)(key >> 32); r.val = (uint32_t)iv; }
 __device__ __forceinline__ void kh_rec_get(const ulonglong2& r, uint64_t& key, unsigned long long& iv) { key = r.x; iv = r.y; }
 __device__ __forceinline__ void kh_rec_get(const KhRec12& r, uint64_t& key, unsigned long long& iv) { key = r.klo | ((uint64_t)r.khi << 32); iv = r.val; }
-template <bool R12> struct KhRecOf { typedef ulonglong2 type; };
-template <> struct KhRecOf<true> { typedef KhRec12 type; };
-template <int HASH, bool R12>
+// record kinds: 0 = 16 bytes (key, position << 32 | value); 1 = 12 bytes (key, value): duplicate-free batch into an empty table;
+// 2 = 8 bytes (key): a counting insert whose values are the constant 1 (Reducer = std::plus needs neither value nor position) --
+// half the partition traffic of the k-mer counter's batches
+struct KhRec8 { uint64_t key; };
+__device__ __forceinline__ void kh_rec_set(KhRec8& r, uint64_t key, unsigned long long) { r.key = key; }
+__device__ __forceinline__ void kh_rec_get(const KhRec8& r, uint64_t& key, unsigned long long& iv) { key = r.key; iv = 0; }
+template <int RK> struct KhRecOf { typedef ulonglong2 type; };
+template <> struct KhRecOf<1> { typedef KhRec12 type; };
+template <> struct KhRecOf<2> { typedef KhRec8 type; };
+template <int HASH, int RK>
 __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P) {
-  typedef typename KhRecOf<R12>::type Rec;
+  constexpr bool R12 = RK != 0;                   // (no stream positions in the records)
+  typedef typename KhRecOf<RK>::type Rec;
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
   __shared__ Rec lrec[KH_PART_STAGE];
   __shared__ uint16_t ld[KH_PART_STAGE];
@@ -1092,7 +1100,8 @@ struct KhSrcSet {
   uint64_t slot[KH_MAX_SRC];             // != 0: histogram-free source: partition q = rec[s][q * slot, cur[s][q]) (clamped to the slot)
   const unsigned long long* cur[KH_MAX_SRC];
   uint32_t n;                            // number of sources (>= 1)
-  uint32_t rec12;                        // != 0 (one histogram-free source only): rec[0] holds KhRec12 records (key, value; no stream position)
+  uint32_t rec12;                        // 1 (one histogram-free source only): rec[0] holds KhRec12 records (key, value; no stream position)
+                                         // 2 (one source, counting insert, general path only): rec[0] holds 8-byte keys, every value is 1
   const uint64_t* merged_off;            // [nparts+1] sum over the sources of off[s][q]: where partition q's OUTPUT list starts
 };
 // per-workgroup view of partition q.  One source (every plain insert): the slice is addressed directly through a
@@ -1103,6 +1112,7 @@ struct KhSrcSet {
 struct KhSrcView {
   const ulonglong2* one;                 // != nullptr: single source, slice start
   const KhRec12* one12;                  // != nullptr: single source of 12-byte records, slice start
+  const uint64_t* one8;                  // != nullptr: single source of 8-byte keys (value 1 each), slice start
   uint32_t m;                            // records of the partition
   uint32_t n;                            // sources
 };
@@ -1110,7 +1120,7 @@ template <bool ALLOW12 = false>
 __device__ __forceinline__ KhSrcView kh_src_setup(const KhSrcSet& S, uint32_t q, const ulonglong2** s_ptr, uint32_t* s_cum) {
   KhSrcView V;
   V.n = S.n;
-  V.one12 = nullptr;
+  V.one12 = nullptr; V.one8 = nullptr;
   if (S.n == 1) {
     if (S.slot[0]) {
       const uint64_t b = (uint64_t)q * S.slot[0];
@@ -1137,6 +1147,21 @@ __device__ __forceinline__ KhSrcView kh_src_setup(const KhSrcSet& S, uint32_t q,
   __syncthreads();
   V.one = nullptr;
   V.m = s_cum[S.n];
+  return V;
+}
+// one source of 8-byte keys (counting insert, k_dedup only)
+__device__ __forceinline__ KhSrcView kh_src_setup8(const KhSrcSet& S, uint32_t q) {
+  KhSrcView V;
+  V.n = 1; V.one = nullptr; V.one12 = nullptr;
+  if (S.slot[0]) {
+    const uint64_t b = (uint64_t)q * S.slot[0], c = S.cur[0][q] - b;
+    V.one8 = reinterpret_cast<const uint64_t*>(S.rec[0]) + b;
+    V.m = (uint32_t)(c < S.slot[0] ? c : S.slot[0]);
+  } else {
+    const uint64_t b = S.off[0][q];
+    V.one8 = reinterpret_cast<const uint64_t*>(S.rec[0]) + b;
+    V.m = (uint32_t)(S.off[0][q + 1] - b);
+  }
   return V;
 }
 // several sources: where record i of the partition lives (the loads themselves are issued by the caller, all of a lane's together)
@@ -1179,7 +1204,7 @@ struct KhDedupParams {
 // LDS budget 52 KB (3 workgroups per CU): the partition's records are staged in LDS (16 B each) and the hash set
 // holds 32-bit record indices, so a set entry is claimed with one 32-bit CAS and duplicates fold into the claimed
 // record's (idx|val) word with one 64-bit min/max/add.
-template <int KIND, int HASH>
+template <int KIND, int HASH, bool REC8 = false>      // REC8: the one source holds 8-byte keys, every value 1 (counting insert)
 __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ unsigned long long lk[KH_DD_M];
   __shared__ unsigned long long liv[KH_DD_M];
@@ -1191,7 +1216,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ uint32_t s_cum[KH_MAX_SRC + 1];
   const uint32_t tid = threadIdx.x;
   const uint32_t q = blockIdx.x;
-  const KhSrcView V = kh_src_setup(P.src, q, s_ptr, s_cum);
+  const KhSrcView V = REC8 ? kh_src_setup8(P.src, q) : kh_src_setup(P.src, q, s_ptr, s_cum);
   const uint32_t m = V.m;
   const uint64_t beg = P.src.merged_off[q];            // output list of this partition
   const uint64_t mask = P.T.cap - 1;
@@ -1227,7 +1252,10 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           if (take_n) {                                    // (an empty partition has nothing to read: m - 1 would wrap)
             ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
             const uint32_t last = m - 1u;
-            if (V.one) {
+            if (REC8) {       // counting insert: 8-byte keys, every value 1
+#pragma unroll
+              for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = pos + it * KH_CHUNK_THREADS + tid; rr[it] = make_ulonglong2(V.one8[i < last ? i : last], 1ull); }
+            } else if (V.one) {
 #pragma unroll
               for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = pos + it * KH_CHUNK_THREADS + tid; rr[it] = V.one[i < last ? i : last]; }
             } else {       // several feeds: find every record's source first, then request them together
@@ -1254,7 +1282,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           bool take = false;
           unsigned long long key = 0, iv = 0;
           if (i < m) {
-            const ulonglong2 rr = kh_src_load(V, s_ptr, s_cum, i);
+            const ulonglong2 rr = REC8 ? make_ulonglong2(V.one8[i], 1ull) : kh_src_load(V, s_ptr, s_cum, i);
             key = rr.x; iv = rr.y;
             take = R == 1 || (uint32_t)((kh_fmix64(key + 0x9E3779B97F4A7C15ull) >> 32) % R) == r;
           }

@@ -500,7 +500,7 @@ struct Partitioned {
   uint64_t slot;                                // != 0: histogram-free layout: partition q = rec[q * slot, cursor[q])
   const unsigned long long* cursor;
   uint32_t* overflow;                           // device flag: a partition outgrew its slot (the batch must be redone with exact offsets)
-  bool rec12;                                   // rec holds 12-byte (key, value) records (histogram-free layout only)
+  int rec12;                                    // 0: 16-byte records; 1: 12-byte (key, value) (histogram-free layout only); 2: 8-byte keys (counting insert)
 };
 // slot of a histogram-free partition with mean m records: m + 7 sigma (hashed keys: Poisson) + a little
 inline uint64_t slack_slot(double mean) { return (uint64_t)(mean + 7.0 * std::sqrt(mean) + 16.0); }
@@ -515,9 +515,9 @@ inline uint64_t part_buffer_records(uint64_t n, uint32_t PB, bool allow_slack) {
 // stream position of the first pair (pairs fed before it in a streamed insert).  Asynchronous on the table's stream.
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
                           uint32_t vconst, uint64_t n, uint64_t idx_base, uint32_t PB, ulonglong2* tmp, ulonglong2* fin, Partitioned& out,
-                          bool allow_slack = false, bool rec12 = false, const SlackShared* shared = nullptr) {
+                          bool allow_slack = false, int rec12 = 0, const SlackShared* shared = nullptr) {
   const uint32_t nparts = 1u << PB;
-  out.slot = 0; out.cursor = nullptr; out.overflow = nullptr; out.rec12 = false;
+  out.slot = 0; out.cursor = nullptr; out.overflow = nullptr; out.rec12 = 0;
   if (shared || part_buffer_records(n, PB, allow_slack) != n) {
     // ---- histogram-free two-pass partition: hashed keys fill the 2^PB partitions evenly, so every partition
     // gets a fixed slot of mean + 7 sigma records and the passes reserve space with their cursors alone: no histogram sweep
@@ -544,8 +544,9 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
     P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.cursor = cur1; P.orec = tmp; P.slot = slot1; P.overflow = ovf; P.dump = slot1 * nb1;
     { Launch L(t, "k_part_scatter");
-      if (rec12) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, true>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
-      else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); } }
+      if (rec12 == 1) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 1>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
+      else if (rec12 == 2) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 2>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
+      else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 0>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); } }
     { Launch L(t, "k_make_tiles");
       hipLaunchKernelGGL(k_make_tiles, dim3(1), dim3(1024), 0, t->stream, (const uint64_t*)nullptr, nb1, tiles, ntiles_dev, (const unsigned long long*)cur1, slot1); }
     KhPartParams Q = P;
@@ -553,13 +554,15 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
     Q.shift = 0; Q.nb = nb2; Q.cursor = cur2; Q.orec = fin; Q.slot = slot; Q.dump = slot * nparts;
     { Launch L(t, "k_part_scatter");
-      if (rec12) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, true>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
-      else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); } }
+      if (rec12 == 1) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 1>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
+      else if (rec12 == 2) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 2>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
+      else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 0>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); } }
     HIPCHK(hipGetLastError());
     out.rec = fin; out.part_off = starts; out.PB = PB; out.nparts = nparts; out.spare = tmp;
     out.slot = slot; out.cursor = cur2; out.overflow = ovf; out.rec12 = rec12;
     return KH_OK;
   }
+  if (rec12 == 1 || (rec12 == 2 && PB > 18)) return fail(t, KH_ERR_HIP, "internal: record kind not available with exact offsets");
   ulonglong2* ar = nullptr; ulonglong2* br = fin;
   const uint32_t B1 = PB <= 11 ? PB : (PB + 1) / 2, B2 = PB - B1;
   const uint32_t nb1 = 1u << B1, nb2 = 1u << B2;
@@ -608,7 +611,9 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     HIPCHK(hipMemcpyAsync(cur1, off1, sizeof(uint64_t) * nb1, hipMemcpyDeviceToDevice, t->stream));
   }
   { Launch L(t, "k_part_scatter");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
+    if (rec12 == 2) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 2>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
+    else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 0>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); } }
+  out.rec12 = rec12 == 2 ? 2 : 0;
   if (B2 == 0) {
     out.rec = ar; out.part_off = off1; out.PB = PB; out.nparts = nparts;
     out.spare = tmp;
@@ -631,7 +636,8 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   }
   HIPCHK(hipMemcpyAsync(cur2, off2, sizeof(uint64_t) * nparts, hipMemcpyDeviceToDevice, t->stream));
   { Launch L(t, "k_part_scatter");
-    KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, false>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
+    if (rec12 == 2) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 2>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }
+    else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 0>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); } }
   HIPCHK(hipGetLastError());
   out.rec = br; out.part_off = off2; out.PB = PB; out.nparts = nparts;
   out.spare = tmp;
@@ -678,6 +684,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   if (PB > 22) return fail(t, KH_ERR_UNSUPPORTED, "batch would need more than 2^22 partitions");
   const size_t keep_blk = t->blk, keep_off = t->off;
   int first_attempt = 0;
+  bool dup_heavy = false;
   if (part_buffer_records(n, PB, true) != n) {
     // histogram-free partition only for batches a sample finds (nearly) free of duplicates
     unsigned long long* sset; uint32_t* dups;
@@ -688,7 +695,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
       hipLaunchKernelGGL(k_sample_dups, dim3(KH_SAMPLE_N / 256), dim3(256), 0, t->stream, kbase, kstride, n, sset, dups); }
     HIPCHK(hipMemcpyAsync(t->hpin + 31, dups, 4, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
-    if ((uint32_t)t->hpin[31] >= 8u) first_attempt = 1;
+    if ((uint32_t)t->hpin[31] >= 8u) { first_attempt = 1; dup_heavy = true; }
     t->batch_nodup = (uint32_t)t->hpin[31] == 0u;
     t->blk = keep_blk; t->off = keep_off;
   } else first_attempt = 1;
@@ -699,19 +706,25 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     // no duplicate in the sample and an empty table ahead of the one-launch build: the records need no stream position
     // (12 bytes instead of 16); whatever that build cannot take (a duplicate after all, a dense chunk) repeats the batch
     const bool rec12 = slack && t->batch_nodup && nodup_build_applies(t, cap_u, PB, mode);
-    ulonglong2 *tmp, *fin;
-    { char *a, *b; const size_t rb = rec12 ? sizeof(KhRec12) : sizeof(ulonglong2);
+    // a counting insert (Reducer = std::plus, every value 1) of a batch the sample found heavy in duplicates -- the k-mer counter's
+    // batches: the records are the keys alone (8 bytes: neither value nor position is needed), and the general path takes them
+    // directly (the one-launch forms speculate on few duplicates: hopeless here)
+    const bool rec8 = !slack && !rec12 && dup_heavy && mode == INS_PLUS && vbase == nullptr && PB <= 18 && !getenv("KH_DISABLE_REC8");
+    const int kind = rec12 ? 1 : rec8 ? 2 : 0;
+    ulonglong2 *tmp, *fin, *spare;
+    { char *a, *b; const size_t rb = kind == 1 ? sizeof(KhRec12) : kind == 2 ? sizeof(KhRec8) : sizeof(ulonglong2);
       TAKE(a, char, m * rb); TAKE(b, char, m * rb);
-      tmp = reinterpret_cast<ulonglong2*>(a); fin = reinterpret_cast<ulonglong2*>(b); }
+      tmp = reinterpret_cast<ulonglong2*>(a); fin = reinterpret_cast<ulonglong2*>(b); spare = tmp;
+      if (kind == 2) { char* c; TAKE(c, char, m * 12); spare = reinterpret_cast<ulonglong2*>(c); } }     // (lists of distinct keys + counts: 12 bytes per entry)
     Partitioned R;
-    kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R, slack, rec12);
+    kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R, slack, kind);
     if (st != KH_OK) return st;
     KhSrcSet S;
     memset(&S, 0, sizeof(S));
     S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off; S.slot[0] = R.slot; S.cur[0] = R.cursor;
-    S.rec12 = R.rec12 ? 1u : 0u;
+    S.rec12 = (uint32_t)R.rec12;
     t->part_overflow = R.overflow;
-    st = insert_finish(t, S, n, PB, cap_u, mode, forced_cap, tmp, n_new_out, m);
+    st = insert_finish(t, S, n, PB, cap_u, mode, forced_cap, spare, n_new_out, m);
     t->part_overflow = nullptr; t->batch_nodup = false;
     if (st != KH_RETRY_EXACT) return st;
   }
@@ -727,7 +740,7 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   struct { uint32_t nparts; } R; R.nparts = nparts;
   // ---- fused bulk build: empty table, moderate load factor, at least two chunks.  Speculates that the capacity the
   // reference's rule yields equals cap_u (true when the batch holds few duplicates); otherwise falls through.
-  if (fused_build_applies(t, cap_u, PB)) {
+  if (fused_build_applies(t, cap_u, PB) && S.rec12 != 2) {
     const uint32_t nch = (uint32_t)(cap_u >> KH_LB);
     KhSlots nw;
     st = fresh_slots(t, cap_u, nw);
@@ -777,14 +790,14 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
               reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[1], reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[0],
               reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 32)[2]);
     retire_slots(t, nw);      // speculation failed (duplicates, skew): the buffer becomes the spare, general path below
-    if (S.rec12) return KH_RETRY_EXACT;      // (the general path needs the stream positions: repartition with 16-byte records)
+    if (S.rec12 == 1) return KH_RETRY_EXACT;      // (the general path needs the stream positions: repartition with 16-byte records)
   }
-  if (S.rec12) return fail(t, KH_ERR_HIP, "internal: 12-byte records outside the bulk build");
+  if (S.rec12 == 1) return fail(t, KH_ERR_HIP, "internal: 12-byte records outside the bulk build");
   // ---- fused insert into a NON-empty Robin Hood table: every chunk stages its current elements (home from the info byte)
   // next to the batch's records of the same chunk, folds them together (an element of the table beats every record), and
   // lays the chunk out -- no membership probes at random into HBM (k_dedup), no separate re-layout.  Speculates, like the
   // bulk build, that the capacity the reference's rule yields equals cap_u.
-  if (t->lsize > 0 && (mode == INS_FIRST || mode == INS_PLUS) && !forced_cap && !g_disable_fused_rebuild &&
+  if (t->lsize > 0 && S.rec12 != 2 && (mode == INS_FIRST || mode == INS_PLUS) && !forced_cap && !g_disable_fused_rebuild &&
       t->cur.cap >= 2 * (uint64_t)KH_L && (cap_u == t->cur.cap || cap_u == 2 * t->cur.cap) && t->max_lf <= 0.9f &&
       PB == log2u(cap_u >> KH_LB) && t->lsize + n <= threshold(cap_u, 0.92f)) {
     const size_t keep_blk = t->blk, keep_off = t->off;
@@ -847,7 +860,8 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   D.count_cap = fuse ? cap_u : 0; D.PB = PB; D.homecnt = pre.homecnt; D.sumA = pre.sumA; D.sumN = pre.sumN;
   D.T = t->cur; D.seed = t->seed; D.table_empty = t->lsize == 0 ? 1 : 0; D.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST; D.flags = flags;
   { Launch L(t, "k_dedup");
-    KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
+    if (S.rec12 == 2) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH, true>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
+    else { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); } }
   { Launch L(t, "k_scan");
     hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, cnt_new, (uint64_t)R.nparts, noff); }
   HIPCHK(hipGetLastError());

@@ -702,6 +702,32 @@ def test_tiny_and_odd_initial_capacities(oracle, kname, cls, kind, cap0):
     g.close()
 
 
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_counting_insert_with_key_only_records(kname, cls, kind, monkeypatch):
+    """Reducer = std::plus with the implicit value 1 on a batch the sample finds heavy in duplicates (the k-mer counter's batches):
+    the partition records are the keys alone (8 bytes).  Counts equal numpy's, and the table is bit-identical to the one the
+    16-byte-record path builds (KH_DISABLE_REC8), for a batch into an empty table and a second one into the populated table."""
+    rng = np.random.default_rng(11)
+    uni = W.distinct_u64(1_200_000, seed=21)
+    b1 = uni[rng.integers(0, 800_000, 5_000_000)]
+    b2 = uni[rng.integers(400_000, 1_200_000, 5_000_000)]
+    states = []
+    for disable in (False, True):
+        if disable:
+            monkeypatch.setenv("KH_DISABLE_REC8", "1")
+        g = cls(128, 0.35, 0.8)
+        g.profile_enable(True)
+        g.insert_reduce_plus(dev(b1))
+        assert "k_part_hist" in g.profile() and "k_dedup" in g.profile()          # sampled as duplicate-heavy: exact offsets, general path
+        g.insert_reduce_plus(dev(b2))
+        sk, sv = g.sorted_items()
+        uk, cnt = np.unique(np.concatenate([b1, b2]), return_counts=True)
+        assert np.array_equal(sk, uk) and np.array_equal(sv, cnt.astype(np.uint32))
+        states.append((g.capacity(), g.export_info().copy()))
+        g.close()
+    assert states[0][0] == states[1][0] and np.array_equal(states[0][1], states[1][1])
+
+
 def test_shard_plan_equals_per_piece_permute():
     """kh_shard_plan: one count sweep for a batch cut into pieces; every piece's permutation and counts equal kh_shard_permute run on
     that piece alone (stable, same destination ranks)"""
