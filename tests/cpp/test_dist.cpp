@@ -38,7 +38,10 @@ static std::vector<std::pair<uint64_t, uint32_t> > contents(kh_table* t) {
   return out;
 }
 
-static void local_group(int P, int pieces, size_t n_per_rank) {
+// keymode 0: every rank draws with replacement from one universe (duplicates everywhere: exact layout of the streamed insert);
+// 1: globally distinct keys (the repeatable streamed insert's histogram-free layout holds); 2: distinct, but 300 keys of rank 0
+// come again late in rank 1's input -- the first piece's sample cannot see them: KH_ERR_RETRY inside khd_insert, pieces fed again
+static void local_group(int P, int pieces, size_t n_per_rank, int keymode = 0) {
   std::vector<khd_map*> maps(P);
   OK(khd_create_local(maps.data(), P, 0, KH_KIND_ROBINHOOD, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, KH_HASH_MURMUR3_X86_128_LO64, KHD_DIST_SEED));
   // every rank draws from one universe (cross-rank duplicates), own order, own values
@@ -48,8 +51,13 @@ static void local_group(int P, int pieces, size_t n_per_rank) {
   for (auto& u : universe) u = splitmix(us);
   for (int r = 0; r < P; ++r) {
     uint64_t s = 99 + r;
-    for (size_t i = 0; i < n_per_rank; ++i) { keys[r].push_back(universe[splitmix(s) % universe.size()]); vals[r].push_back(uint32_t(r * 10000000u + i)); }
+    for (size_t i = 0; i < n_per_rank; ++i) {
+      uint64_t d = (uint64_t(r + 1) << 40) + i;
+      keys[r].push_back(keymode == 0 ? universe[splitmix(s) % universe.size()] : splitmix(d));
+      vals[r].push_back(uint32_t(r * 10000000u + i));
+    }
   }
+  if (keymode == 2) for (size_t i = 0; i < 300; ++i) keys[1][n_per_rank - 1000 + i] = keys[0][10 + i];
   // the single table that sees the pairs in receive order: piece-major, then source rank, then position
   kh_table* model = nullptr;
   OK(kh_create(&model, KH_KIND_ROBINHOOD, 8, 4, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, 0));
@@ -70,6 +78,7 @@ static void local_group(int P, int pieces, size_t n_per_rank) {
   std::vector<std::vector<uint64_t> > q(P);
   for (int r = 0; r < P; ++r) { uint64_t s = 7 + r; for (size_t i = 0; i < 3000; ++i) q[r].push_back(i % 3 ? keys[r][splitmix(s) % n_per_rank] : (splitmix(s) | 1ull << 63)); }
   std::vector<uint64_t> inserted(P), erased(P), gsize(P), gsize2(P);
+  std::vector<int> refed(P, 0);
   std::vector<std::vector<uint64_t> > ck_out(P), fk_out(P); std::vector<std::vector<uint8_t> > c_out(P), f_out(P); std::vector<std::vector<uint32_t> > v_out(P);
   std::vector<std::thread> th;
   for (int r = 0; r < P; ++r)
@@ -91,10 +100,13 @@ static void local_group(int P, int pieces, size_t n_per_rank) {
       OK(khd_size(m, &gsize2[r]));
       char buf[512]; OK(khd_phase_ms(m, buf, sizeof(buf)));
       if (r == 0) CHECK(std::strstr(buf, "exchange") && std::strstr(buf, "permute"));
+      if (r == 0 && keymode == 1 && pieces > 1) CHECK(!std::strstr(buf, "refeed"));
+      if (keymode == 2 && pieces > 1) refed[r] = std::strstr(buf, "refeed") != nullptr;
       CHECK(hipStreamSynchronize(st) == hipSuccess);
       hipFree(dk); hipFree(dv); hipFree(dq); hipFree(ok); hipFree(oc); hipFree(ov); hipFree(of);
     });
   for (auto& t : th) t.join();
+  if (keymode == 2 && pieces > 1) { int any = 0; for (int r = 0; r < P; ++r) any |= refed[r]; CHECK(any); }      // some rank had to feed its pieces again
   // (a) erase: every queried key that existed is gone, once
   std::vector<uint64_t> allq;
   for (int r = 0; r < P; ++r) allq.insert(allq.end(), q[r].begin(), q[r].end());
@@ -174,6 +186,8 @@ int main() {
   local_group(4, 3, 60000);
   local_group(3, 1, 20000);      // rank = hash % p (not a power of two), one exchange then one bulk insert
   local_group(2, 5, 300000);
+  local_group(2, 4, 4000000, 1);   // large enough for the histogram-free layout of the pieces (>= 2^20 pairs per rank at 2^12 partitions)
+  local_group(2, 4, 4000000, 2);   // ... and its retry
   std::printf("all dist tests passed\n");
   return 0;
 }
