@@ -274,10 +274,12 @@ def run_rank(args):
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # (bounded: a collective that does not complete within 3 minutes ends the rank with an error instead of a silent hang)
+        import datetime
         if REHEARSAL:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=180))
         if dist.get_world_size() != args.gpus:
             print("[bench] process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus), file=sys.stderr, flush=True)
             return 2
