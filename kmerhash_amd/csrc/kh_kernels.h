@@ -1194,6 +1194,10 @@ struct KhDedupParams {
   // capacity decided after this kernel equals count_cap
   uint64_t count_cap; uint32_t PB; uint16_t* homecnt; long long* sumA; long long* sumN;
   int table_empty;                                               // size() == 0: skip the membership probes
+  // > 1: the xcd_group consecutive partitions q that probe the SAME chunk of the (smaller) current table are given to workgroups b,
+  // b + 8, b + 16, ... -- one XCD under the observed round-robin placement (speed only): their membership probes then share
+  // the sectors of that chunk in one L2 instead of fetching them once per XCD
+  uint32_t xcd_group;
   int mode;                                                      // KH_DEDUP_FIRST : insert (first value wins, emit keys the table lacks)
                                                                  // KH_DEDUP_LAST  : kh_update assign pass (last value wins, written in place)
                                                                  // KH_DEDUP_PLUS  : reducer std::plus: values of equal keys are summed; keys the
@@ -1215,7 +1219,11 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ const ulonglong2* s_ptr[KH_MAX_SRC];
   __shared__ uint32_t s_cum[KH_MAX_SRC + 1];
   const uint32_t tid = threadIdx.x;
-  const uint32_t q = blockIdx.x;
+  uint32_t q = blockIdx.x;
+  if (P.xcd_group > 1) {       // (host: power of two, gridDim.x a multiple of 8 * xcd_group)
+    const uint32_t G = P.xcd_group, x = q & 7u, row = q >> 3;
+    q = (((row / G) << 3) + x) * G + (row & (G - 1u));
+  }
   const KhSrcView V = REC8 ? kh_src_setup8(P.src, q) : kh_src_setup(P.src, q, s_ptr, s_cum);
   const uint32_t m = V.m;
   const uint64_t beg = P.src.merged_off[q];            // output list of this partition

@@ -859,6 +859,15 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   }
   D.count_cap = fuse ? cap_u : 0; D.PB = PB; D.homecnt = pre.homecnt; D.sumA = pre.sumA; D.sumN = pre.sumN;
   D.T = t->cur; D.seed = t->seed; D.table_empty = t->lsize == 0 ? 1 : 0; D.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST; D.flags = flags;
+  D.xcd_group = 0;
+  if (t->lsize > 0 && t->cur.cap > KH_L && !getenv("KH_DISABLE_XCD_GROUP")) {
+    // partitions are cut for cap_u, the probes go to the (smaller) current table: 2^(PB - k) consecutive partitions share one of its chunks
+    const uint32_t k_tab = log2u(t->cur.cap >> KH_LB);
+    if (PB > k_tab) {
+      const uint32_t G = std::min<uint32_t>(1u << (PB - k_tab), 16u);
+      if (R.nparts % (8u * G) == 0) D.xcd_group = G;
+    }
+  }
   { Launch L(t, "k_dedup");
     if (S.rec12 == 2) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH, true>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
     else { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); } }
