@@ -579,6 +579,7 @@ struct KhPartParams {
   uint64_t slot;
   uint64_t dump;                           // first record of the dump area in orec (KH_PART_TILE records)
   uint32_t* overflow;
+  int xcd_swizzle;                         // eight consecutive tiles per XCD (adjacent output runs meet in one L2; speed only)
   // (k_part_scatter<HASH, true>: rec_in / orec hold KhRec12 records instead -- histogram-free mode only)
 };
 
@@ -672,7 +673,12 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t ntiles = P.tiles ? *P.ntiles_dev : P.ntiles;
   if (blockIdx.x >= ntiles) return;
-  KhTile d = kh_get_tile(P, blockIdx.x);
+  uint32_t tile = blockIdx.x;
+  if (P.xcd_swizzle && (tile | 63u) < ntiles) {      // (whole groups of 64 tiles only) eight CONSECUTIVE tiles per XCD: b, b + 8, ... share one
+    const uint32_t x = tile & 7u, j = (tile >> 3) & 7u;
+    tile = (tile & ~63u) + x * 8u + j;
+  }
+  KhTile d = kh_get_tile(P, tile);
   if (d.len == 0) return;
   for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) hist[i] = 0;
   __syncthreads();

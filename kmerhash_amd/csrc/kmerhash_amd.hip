@@ -505,6 +505,9 @@ struct Partitioned {
 // slot of a histogram-free partition with mean m records: m + 7 sigma (hashed keys: Poisson) + a little
 inline uint64_t slack_slot(double mean) { return (uint64_t)(mean + 7.0 * std::sqrt(mean) + 16.0); }
 const bool g_disable_slack = getenv("KH_DISABLE_SLACK_PARTITION") != nullptr;      // test hook: exact offsets always
+// eight consecutive partition tiles per XCD (blocks b, b + 8, ... share one): the adjacent output runs of consecutive tiles meet in
+// one L2 (-3 % scatter time, measured A/B); KH_DISABLE_XCD_SWIZZLE=1 turns it off
+const int g_xcd_swizzle = getenv("KH_DISABLE_XCD_SWIZZLE") ? 0 : 1;
 // records the two buffers of partition_batch must hold
 inline uint64_t part_buffer_records(uint64_t n, uint32_t PB, bool allow_slack) {
   if (!allow_slack || g_disable_slack || PB <= 11 || n < (uint64_t(256) << PB)) return n;
@@ -540,6 +543,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     KhPartParams P;
     memset(&P, 0, sizeof(P));
     P.idx_base = idx_base;
+    P.xcd_swizzle = g_xcd_swizzle;
     P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.n = n;
     P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
     P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.cursor = cur1; P.orec = tmp; P.slot = slot1; P.overflow = ovf; P.dump = slot1 * nb1;
@@ -572,6 +576,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   KhPartParams P;
   memset(&P, 0, sizeof(P));
   P.idx_base = idx_base;
+  P.xcd_swizzle = g_xcd_swizzle;
   P.kbase = kbase; P.kstride = kstride; P.vbase = vbase; P.vstride = vstride; P.vconst = vconst; P.rec_in = nullptr; P.n = n;
   P.tiles = nullptr; P.ntiles_dev = nullptr; P.ntiles = (uint32_t)((n + KH_PART_TILE - 1) / KH_PART_TILE);
   P.seed = t->seed; P.PB = PB; P.shift = B2; P.nb = nb1; P.counts = counts1; P.cursor = cur1;
