@@ -902,6 +902,15 @@ __global__ void k_sample_dups(const char* __restrict__ kbase, uint32_t kstride, 
 }
 
 // histogram-free partition: cursor[j] = j * slot (and, if asked, the same values as partition start offsets)
+// both levels of a histogram-free partition in one launch: level-1 cursors, level-2 cursors + slot starts, the overflow flag
+__global__ void k_init_cursors2(unsigned long long* __restrict__ cur1, uint64_t n1, uint64_t slot1, unsigned long long* __restrict__ cur2,
+                                uint64_t* __restrict__ starts, uint64_t n2, uint64_t slot2, uint32_t* __restrict__ ovf) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n1) cur1[i] = i * slot1;
+  if (i < n2) cur2[i] = i * slot2;
+  if (i <= n2) starts[i] = i * slot2;
+  if (i == 0) *ovf = 0u;
+}
 __global__ void k_init_cursors(unsigned long long* __restrict__ cursor, uint64_t* __restrict__ starts, uint64_t n, uint64_t slot) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) cursor[i] = i * slot;
@@ -2164,8 +2173,15 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
 }
 
 // carry-in of chunk 0 = run-over of the last chunk (circular table)
-__global__ void k_fused_tail_carry(const unsigned long long* __restrict__ pub, uint32_t nch, long long* __restrict__ xcarry0) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) xcarry0[0] = (long long)((pub[nch - 1] >> 32) & 0x7FFFFFFFull);
+// (also what the tail placement of chunk 0 needs besides: its list offsets {0, 0} and its list length = the count field of pub[0] --
+//  one launch instead of a kernel, a fill and a copy)
+__global__ void k_fused_tail_carry(const unsigned long long* __restrict__ pub, uint32_t nch, long long* __restrict__ xcarry0,
+                                   uint64_t* __restrict__ noff0 = nullptr, uint32_t* __restrict__ ncnt0 = nullptr) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    xcarry0[0] = (long long)((pub[nch - 1] >> 32) & 0x7FFFFFFFull);
+    if (noff0) { noff0[0] = 0; noff0[1] = 0; }
+    if (ncnt0) ncnt0[0] = (uint32_t)pub[0];
+  }
 }
 
 // totals of a fused build: sum of the per-chunk counts (low word of the published granules) and max of maxidx.

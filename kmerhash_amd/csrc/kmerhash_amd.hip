@@ -334,13 +334,12 @@ struct FusedRun { unsigned long long* totals; uint32_t* flags; };
 kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw, uint32_t PB_tail, const char* name, FusedRun* out) {
   const uint32_t nch = (uint32_t)(nw.cap >> KH_LB);
   char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
-  const size_t sz_pub = (size_t)nch * 8, sz_all = sz_pub + 256;
+  const size_t sz_pub = (size_t)nch * 8, sz_ctl = sz_pub + 256, sz_all = sz_ctl + (size_t)nch * 4;      // granules, control words, maxidx: ONE fill
   TAKE(blk, char, sz_all);
-  TAKE(maxidx, uint32_t, nch);
+  maxidx = reinterpret_cast<uint32_t*>(blk + sz_ctl);
   TAKE(ck0, uint64_t, KH_DD_M); TAKE(cv0, uint32_t, KH_DD_M); TAKE(hc0, uint16_t, KH_L); TAKE(xc0, long long, 1);
   TAKE(noff0, uint64_t, 2); TAKE(ncnt0, uint32_t, 1);
   HIPCHK(hipMemsetAsync(blk, 0, sz_all, t->stream));
-  HIPCHK(hipMemsetAsync(maxidx, 0, sizeof(uint32_t) * nch, t->stream));
   F.New = nw; F.seed = t->seed;
   F.pub = reinterpret_cast<unsigned long long*>(blk);
   unsigned long long* totals = reinterpret_cast<unsigned long long*>(blk + sz_pub);   // 2 x u64 (k_fused_totals)
@@ -357,9 +356,7 @@ kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw
     hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
   { // chunk 0: placed now that the last chunk's run-over is known (one workgroup of the general placement kernel)
     Launch L(t, "k_fused_tail");
-    hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0);
-    HIPCHK(hipMemsetAsync(noff0, 0, 16, t->stream));
-    HIPCHK(hipMemcpyAsync(ncnt0, F.pub, 4, hipMemcpyDeviceToDevice, t->stream));      // list length of partition 0 = count field of pub[0]
+    hipLaunchKernelGGL(k_fused_tail_carry, dim3(1), dim3(64), 0, t->stream, F.pub, nch, xc0, noff0, ncnt0);      // (+ list offsets {0, 0}, list length = count field of pub[0])
     KhRebuildParams T0;
     memset(&T0, 0, sizeof(T0));
     T0.Old = kNoSlots; T0.New = nw; T0.ck = ck0; T0.cv = cv0; T0.noff = noff0; T0.ncnt = ncnt0; T0.PB = PB_tail;
@@ -535,11 +532,8 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     if (shared) { cur2 = shared->cur2; starts = shared->starts; ovf = shared->ovf; }
     else { TAKE(cur2, unsigned long long, nparts); TAKE(starts, uint64_t, (size_t)nparts + 1); TAKE(ovf, uint32_t, 1); }
     TAKE(tiles, KhTile, max_tiles); TAKE(ntiles_dev, uint32_t, 1);
-    hipLaunchKernelGGL(k_init_cursors, dim3((nb1 + 255) / 256), dim3(256), 0, t->stream, cur1, (uint64_t*)nullptr, (uint64_t)nb1, slot1);
-    if (!shared) {
-      HIPCHK(hipMemsetAsync(ovf, 0, 4, t->stream));
-      hipLaunchKernelGGL(k_init_cursors, dim3((nparts + 256) / 256), dim3(256), 0, t->stream, cur2, starts, (uint64_t)nparts, slot);
-    }
+    if (shared) hipLaunchKernelGGL(k_init_cursors, dim3((nb1 + 255) / 256), dim3(256), 0, t->stream, cur1, (uint64_t*)nullptr, (uint64_t)nb1, slot1);
+    else hipLaunchKernelGGL(k_init_cursors2, dim3((nparts + 256) / 256), dim3(256), 0, t->stream, cur1, (uint64_t)nb1, slot1, cur2, starts, (uint64_t)nparts, slot, ovf);
     KhPartParams P;
     memset(&P, 0, sizeof(P));
     P.idx_base = idx_base;
