@@ -118,7 +118,8 @@ kh_status kh_update(kh_table* t, const void* keys, const void* vals, uint64_t n,
  *      kh_insert_feed returns; device buffers must stay valid until the work queued on the table's stream has consumed them
  *      (kh_insert_end synchronises). */
 kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus);
-/* flags: KH_INS_REDUCE_PLUS = kh_insert_begin's reduce_plus.  KH_INS_REPEATABLE: the caller keeps every piece it feeds (valid and
+/* (same reference interface as kh_insert_begin: insert_no_estimate per received block, incremental_mxx.hpp:3437-3645)
+ * flags: KH_INS_REDUCE_PLUS = kh_insert_begin's reduce_plus.  KH_INS_REPEATABLE: the caller keeps every piece it feeds (valid and
  *      unchanged) until kh_insert_end has returned and can feed them again.  The library may then partition the pieces without a
  *      histogram pass into slots they share (and without stream positions when a sample of the first piece shows no duplicate key);
  *      if that does not hold for the batch -- skewed or duplicated keys -- kh_insert_end returns KH_ERR_RETRY with the table
@@ -182,8 +183,9 @@ kh_status kh_shard_permute_transformed(kh_hash hash, uint64_t seed, kh_key_trans
                                        const uint64_t* keys_dev, const uint32_t* vals_dev, uint64_t n,
                                        uint64_t* out_keys_dev, uint32_t* out_vals_dev, uint64_t* counts_host, int device, void* hip_stream);
 
-/* ---- a batch that will be exchanged in `pieces` pieces (the pipelined insert): ONE count sweep + scan + host synchronisation for the
- *      whole batch.  bounds_host[pieces+1] receives the piece boundaries (multiples of 4096 pairs, the last one = n),
+/* ---- a batch that will be exchanged in `pieces` pieces (the pipelined insert, khmxx::ialltoallv_and_modify incremental_mxx.hpp:3437-3645):
+ *      the counting half of assign_count_permute (distributed_batched_robinhood_map.hpp:632-741) done ONCE -- one count sweep + scan +
+ *      host synchronisation for the whole batch.  bounds_host[pieces+1] receives the piece boundaries (multiples of 4096 pairs, the last one = n),
  *      counts_host[pieces][nranks] the destination counts of every piece; kh_shard_plan_permute then permutes piece i (pairs
  *      [bounds[i], bounds[i+1]) of the SAME keys/vals arrays, unchanged since the plan was made) into out_* grouped by rank, input
  *      order kept, without counting again and without synchronising.  nranks <= 8.  Same result as kh_shard_permute on the piece. */
