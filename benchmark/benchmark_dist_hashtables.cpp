@@ -88,8 +88,8 @@ static void run_rank(khd_map* m, const Opt& o, int rank, int nranks, Times& T) {
   uint64_t sz = 0;
   OK(khd_size(m, &sz));                                         // (collective: every rank starts the phase together)
   auto t0 = now(); OK(khd_insert(m, dk, dv, count, pieces, 0, &T.inserted)); OK(khd_size(m, &T.size)); auto t1 = now();
-  OK(khd_count(m, dq, count, ok, of)); HIP(hipDeviceSynchronize()); OK(khd_size(m, &sz)); auto t2 = now();
-  OK(khd_find(m, dq, count, ok, ov, of)); HIP(hipDeviceSynchronize()); OK(khd_size(m, &sz)); auto t3 = now();
+  OK(khd_count(m, dq, count, ok, of)); OK(khd_synchronize(m)); OK(khd_size(m, &sz)); auto t2 = now();
+  OK(khd_find(m, dq, count, ok, ov, of)); OK(khd_synchronize(m)); OK(khd_size(m, &sz)); auto t3 = now();
   std::vector<uint8_t> hf(count);
   HIP(hipMemcpy(hf.data(), of, count, hipMemcpyDeviceToHost));
   for (auto b : hf) T.hits += b;

@@ -129,6 +129,11 @@ kh_status kh_insert_begin(kh_table* t, uint64_t n_total, int reduce_plus);
 kh_status kh_insert_begin_ex(kh_table* t, uint64_t n_total, unsigned flags);
 kh_status kh_insert_feed(kh_table* t, const void* keys /*[h|d] u64[n]*/, const void* vals /*[h|d] u32[n]*/, uint64_t n, kh_mem where);
 kh_status kh_insert_end(kh_table* t, uint64_t* n_inserted);
+/* gives up a streamed insert after kh_insert_begin: the pieces fed so far are dropped, nothing is inserted and the table is usable
+ * again (the feeds only write workspace).  What the reference does when an exception leaves ialltoallv_and_modify's block loop
+ * (incremental_mxx.hpp:3437-3645): the partially received batch is simply not inserted.  Synchronises the table's stream (queued
+ * partition kernels may still read the caller's buffers).  No-op without a streamed insert in progress. */
+kh_status kh_insert_abort(kh_table* t);
 
 /* ---- reducer insert: the Reducer = std::plus form of the reference's batched table,
  *      hashmap_robinhood_offsets_reduction::insert(keys, T(1)) / insert(pairs) (robinhood_offset_hashmap_ptr.hpp:85-97,
@@ -195,6 +200,14 @@ kh_status kh_shard_plan_create(kh_shard_plan** out, kh_hash hash, uint64_t seed,
                                int device, void* hip_stream);
 kh_status kh_shard_plan_permute(kh_shard_plan* plan, uint32_t piece, const uint64_t* keys_dev, const uint32_t* vals_dev /* may be NULL */,
                                 uint64_t* out_keys_dev, uint32_t* out_vals_dev, void* hip_stream);
+/* (same reference interface: the permutation half of assign_count_permute, distributed_batched_robinhood_map.hpp:632-741, as the
+ * pipelined queries khmxx::ialltoallv_and_query_one_to_one use it, incremental_mxx.hpp:4403-4669)  piece i written to ITS PLACE in the
+ * layout of the whole batch grouped by rank -- out_* have room for all n pairs and end up, once every piece has been permuted, equal to
+ * kh_shard_permute's output; the part of rank r that piece i contributes is contiguous: it starts at offsets[r][i] and ends at
+ * offsets[r][i + 1] (kh_shard_plan_offsets: [nranks][pieces + 1] positions in that layout). */
+kh_status kh_shard_plan_permute_global(kh_shard_plan* plan, uint32_t piece, const uint64_t* keys_dev, const uint32_t* vals_dev /* may be NULL */,
+                                       uint64_t* out_keys_dev, uint32_t* out_vals_dev, void* hip_stream);
+kh_status kh_shard_plan_offsets(const kh_shard_plan* plan, uint64_t* offsets_host /* [nranks][pieces+1] */);
 void kh_shard_plan_destroy(kh_shard_plan* plan);
 
 /* ---- k-mer generation front end (BenchmarkKmerCounter.cpp:1655-1706 reads sequences through kmerind's

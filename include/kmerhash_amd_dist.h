@@ -18,7 +18,19 @@
  * tests to run p > 1 on a one-GPU box, where RCCL refuses two ranks on one device.
  *
  * All batch arguments are DEVICE pointers on the map's device.  Every entry point below except khd_unique_id, khd_local,
- * khd_last_error and khd_phase_ms is COLLECTIVE: all ranks call it, in the same order.
+ * khd_last_error, khd_phase_ms, khd_set_stream, khd_set_option, khd_synchronize and khd_debug_fail_next is COLLECTIVE: all ranks
+ * call it, in the same order.
+ *
+ * Failures.  The reference runs under MPI, where an exception on one rank ends the job (MPI_Abort).  Here a rank that fails LOCALLY
+ * inside a collective call (allocation, a kh_* call on its table) never leaves its peers waiting: it keeps taking part in the
+ * collectives the call still has to run and skips its local work; status votes -- a word that travels with the count exchange, an
+ * 8-byte all-reduce before the first payload exchange, for insert / erase one after the last payload exchange (no rank builds or erases
+ * when a rank could not send its real pairs: nothing is applied anywhere) and one at the end -- make EVERY rank return a non-OK
+ * status (the failing rank its own, the others the worst status seen; khd_last_error says which).  Only a failure in the build / local
+ * erase itself (the last vote) leaves the ranks that did not fail with their share of the batch applied.  find / count return without waiting for the device: the status of their local part
+ * travels with the last result exchange and is reported by khd_synchronize or by the next collective call.  A failure of the
+ * transport itself (an RCCL error, a peer that does not arrive within KHD_OPT_TIMEOUT_MS) aborts the communicator: the call and
+ * every later one return KH_ERR_HIP.
  */
 #ifndef KMERHASH_AMD_DIST_H_
 #define KMERHASH_AMD_DIST_H_
@@ -46,6 +58,22 @@ kh_status khd_create_local(khd_map** out, int nranks, int device, kh_kind kind, 
                            float min_load_factor, float max_load_factor, kh_hash dist_hash, uint64_t dist_seed);
 kh_status khd_destroy(khd_map* m);
 kh_status khd_set_stream(khd_map* m, void* hip_stream);
+/* options (set them identically on every rank where noted) */
+enum {
+  KHD_OPT_FORCE_COLLECTIVES = 1, /* != 0: a map of ONE rank runs the exchange code of the multi-rank case (count exchange, grouped
+                                    all-to-all-v per piece, votes) instead of the short cut to its local table; also set by the environment
+                                    variable KH_DIST_FORCE_COLLECTIVES=1 at creation.  (Runs every RCCL call of the library on a one-GPU box.) */
+  KHD_OPT_QUERY_PIECES = 2,      /* pieces a find / count batch of THIS rank is exchanged in (1..8; 0 = by size: 4 from 2^22 keys, 2 from
+                                    2^20): the keys of piece i+1 travel while piece i is looked up and its results return
+                                    (khmxx::ialltoallv_and_query_one_to_one, incremental_mxx.hpp:4403-4669).  May differ between ranks. */
+  KHD_OPT_TIMEOUT_MS = 3         /* how long a rank waits for its peers inside a collective before it aborts the communicator (default
+                                    300000; environment KHD_TIMEOUT_MS) */
+};
+kh_status khd_set_option(khd_map* m, int option, long long value);
+/* waits for everything the map has queued (table stream and exchange stream) and returns the status of the last find / count across
+ * ALL ranks (see "Failures" above).  Not collective, but call it on every rank or on none: a rank that has not looked at the
+ * status of the last find / count reports it from its NEXT collective call instead of running that call, and so must all others. */
+kh_status khd_synchronize(khd_map* m);
 const char* khd_last_error(const khd_map* m);
 kh_table* khd_local(khd_map* m); /* this rank's table: kh_size, kh_capacity, kh_to_vector, kh_export_info ... */
 int khd_rank(const khd_map* m);
@@ -58,7 +86,9 @@ int khd_nranks(const khd_map* m);
  * T = ceil(n / 4096): kh_shard_plan), otherwise at n * i / pieces. */
 kh_status khd_insert(khd_map* m, const uint64_t* keys_dev, const uint32_t* vals_dev, uint64_t n, int pieces, int reduce_plus,
                      uint64_t* n_inserted_local);
-/* count_p (:1258): out_keys_dev[n] = the keys grouped by owner rank, out01_dev[n] = 0/1 aligned with them */
+/* count_p (:1258): out_keys_dev[n] = the keys grouped by owner rank, out01_dev[n] = 0/1 aligned with them.
+ * khd_count and khd_find only QUEUE their work: the outputs are complete in the order of the map's stream (khd_set_stream), or after
+ * khd_synchronize, which also reports whether every rank's local part succeeded. */
 kh_status khd_count(khd_map* m, const uint64_t* keys_dev, uint64_t n, uint64_t* out_keys_dev, uint8_t* out01_dev);
 /* find_p (:1619): values (untouched on a miss) and found flags aligned with the permuted keys */
 kh_status khd_find(khd_map* m, const uint64_t* keys_dev, uint64_t n, uint64_t* out_keys_dev, uint32_t* out_vals_dev, uint8_t* out_found_dev);
@@ -66,6 +96,11 @@ kh_status khd_find(khd_map* m, const uint64_t* keys_dev, uint64_t n, uint64_t* o
 kh_status khd_erase(khd_map* m, const uint64_t* keys_dev, uint64_t n, uint64_t* n_erased_local);
 /* sum of the local sizes */
 kh_status khd_size(khd_map* m, uint64_t* global_size);
+
+/* test hook: the next collective call of this rank fails locally at `stage` (1: before the count exchange, 2: on the receive side
+ * before any payload, 3: in the local work between the payload exchanges, 4: in the build at the end of an insert / the local erase) as if an
+ * allocation had failed there.  Used by tests/cpp/test_dist.cpp to check that no rank hangs and every rank reports. */
+kh_status khd_debug_fail_next(khd_map* m, int stage);
 
 /* per-phase device time of this rank since the last call (HIP events; ms): permute, exchange, feed, build, query.
  * Writes up to `cap` bytes of "name ms\n" lines. */

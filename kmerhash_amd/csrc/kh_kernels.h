@@ -1202,6 +1202,11 @@ struct KhDedupParams {
   KhSrcSet src;                                                  // partitioned records (key, idx<<32|val) of every feed
   uint64_t* nk; uint32_t* nv;                                    // outputs, written at src.merged_off[q] + j
   uint32_t* cnt_new;                                             // [nparts]
+  // KH_DEDUP_PLUS into a non-empty table: the keys the table already holds are NOT increased by this kernel (the host may still
+  // have to discard the attempt: a histogram-free partition that overflowed, a failing re-layout).  Their (slot index, sum) pairs
+  // are listed from the END of the partition's output region downwards (nk[end - 1 - j] = slot, nv[end - 1 - j] = sum; new keys
+  // + existing keys <= records of the partition, so the two lists never meet); k_apply_plus adds them once the attempt stands
+  uint32_t* cnt_upd;                                             // [nparts]
   unsigned long long* max_idx_plus1;                             // max (first-occurrence index + 1) over new keys
   KhSlots T; KhSeed seed;
   // speculative fusion of the chunk-count step (empty table, one partition == one chunk of capacity count_cap):
@@ -1228,7 +1233,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __shared__ unsigned long long lk[KH_DD_M];
   __shared__ unsigned long long liv[KH_DD_M];
   __shared__ uint32_t set[KH_HS];               // 0 = empty, else staged record index + 1 (the key's representative)
-  __shared__ uint32_t n_staged, out_count, overflow, max_idx;
+  __shared__ uint32_t n_staged, out_count, upd_count, overflow, max_idx;
   __shared__ uint32_t cnt16[KH_L / 2];          // fused chunk count: two 16-bit home counters per word
   __shared__ KhMP s_wtot[KH_CHUNK_THREADS / 64];
   __shared__ const ulonglong2* s_ptr[KH_MAX_SRC];
@@ -1242,13 +1247,15 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   const KhSrcView V = REC8 ? kh_src_setup8(P.src, q) : kh_src_setup(P.src, q, s_ptr, s_cum);
   const uint32_t m = V.m;
   const uint64_t beg = P.src.merged_off[q];            // output list of this partition
+  const bool plus_live = P.mode == KH_DEDUP_PLUS && !P.table_empty;
+  const uint64_t end = plus_live ? P.src.merged_off[q + 1] : 0;      // (the list of existing keys grows down from here)
   const uint64_t mask = P.T.cap - 1;
   const bool fuse = P.count_cap != 0;
   const uint64_t cmask = P.count_cap - 1;
   const uint32_t Lc = P.count_cap > KH_L ? KH_L : (uint32_t)P.count_cap;
   const uint32_t chunk = P.PB ? (__brev(q) >> (32 - P.PB)) : 0u;      // partition id = bit-reversed chunk id
   const uint64_t Sc = (uint64_t)chunk * Lc;
-  if (m == 0 && !fuse) { if (tid == 0) P.cnt_new[q] = 0; return; }
+  if (m == 0 && !fuse) { if (tid == 0) { P.cnt_new[q] = 0; if (plus_live) P.cnt_upd[q] = 0; } return; }
   // The records are streamed through the staging area in tiles: the distinct keys found so far stay at its front
   // (D of them), the rest is refilled from the stream, folded, and the representatives are compacted to the front
   // again.  A partition of ANY size and multiplicity (1e7 copies of one k-mer are one key of one partition) therefore
@@ -1259,7 +1266,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   static_assert(KH_HS * 4 == KH_DD_M * 8, "set[] doubles as the compaction scratch");
   bool done = false;
   while (!done) {
-    if (tid == 0) { out_count = 0; overflow = 0; max_idx = 0; }
+    if (tid == 0) { out_count = 0; upd_count = 0; overflow = 0; max_idx = 0; }
     if (fuse) for (uint32_t i = tid; i < KH_L / 2; i += KH_CHUNK_THREADS) cnt16[i] = 0;
     for (uint32_t r = 0; r < R; ++r) {
       uint32_t D = 0, pos = 0, ns = 0, rep_mask = 0;
@@ -1350,19 +1357,23 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
       uint32_t my_max = 0;
       for (uint32_t x0 = 0, it = 0; x0 < ns; x0 += KH_CHUNK_THREADS, ++it) {
         const uint32_t x = x0 + tid;
-        bool emit = false;
+        bool emit = false, upd = false;
         unsigned long long key = 0, iv = 0;
+        uint64_t at = KH_NONE;
         if (x < ns && ((rep_mask >> it) & 1u)) {
           key = lk[x]; iv = liv[x];
-          uint64_t at = KH_NONE;
           uint32_t cur_val = 0;
           if (!P.table_empty) {
             const uint64_t h = kh_hash64<HASH>(key, P.seed);
             at = kh_find_pos<KIND>(P.T.s, mask, h & mask, key, &cur_val, P.seed.xk);
           }
           if (P.mode == KH_DEDUP_LAST) { if (at != KH_NONE) P.T.s[at].val = (uint32_t)iv; }   // kh_update's assign pass: store the LAST value
-          else if (P.mode == KH_DEDUP_PLUS && at != KH_NONE) P.T.s[at].val = cur_val + (uint32_t)iv;   // one lane per distinct key: no race
+          else if (P.mode == KH_DEDUP_PLUS && at != KH_NONE) upd = true;      // deferred: (slot, sum) listed, applied by k_apply_plus
           else emit = at == KH_NONE;
+        }
+        if (plus_live) {       // (wave-uniform)
+          const uint32_t upos = kh_wave_append(upd, &upd_count);
+          if (upd) { P.nk[end - 1 - upos] = at; P.nv[end - 1 - upos] = (uint32_t)iv; }
         }
         const uint32_t pos = kh_wave_append(emit, &out_count);
         if (emit) {
@@ -1386,6 +1397,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __syncthreads();
   if (tid == 0) {
     P.cnt_new[q] = out_count;
+    if (plus_live) P.cnt_upd[q] = upd_count;
     if (out_count) atomicMax(P.max_idx_plus1, (unsigned long long)max_idx);
   }
   if (fuse) {      // what k_chunk_count would produce for this chunk
@@ -1405,6 +1417,22 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
     KhMP total;
     kh_block_scan_mp(v, s_wtot, &total);
     if (tid == 0) { P.sumA[chunk] = (long long)Sc + total.A; P.sumN[chunk] = total.n; }
+  }
+}
+
+// the deferred half of a KH_DEDUP_PLUS pass over a non-empty table: every key the table already held gets the sum k_dedup listed for
+// it (sign = +1), or loses it again (sign = -1: the re-layout that followed failed and the table must read as before).  Every slot
+// appears in at most one list entry (a key belongs to one partition and one class): no race.
+__global__ void k_apply_plus(KhSlot* __restrict__ slots, const uint64_t* __restrict__ merged_off, const uint32_t* __restrict__ cnt_upd,
+                             const uint64_t* __restrict__ nk, const uint32_t* __restrict__ nv, uint32_t nparts, int sign) {
+  for (uint32_t q = blockIdx.x; q < nparts; q += gridDim.x) {
+    const uint64_t end = merged_off[q + 1];
+    const uint32_t c = cnt_upd[q];
+    for (uint32_t j = threadIdx.x; j < c; j += blockDim.x) {
+      const uint64_t at = nk[end - 1 - j];
+      const uint32_t d = nv[end - 1 - j];
+      slots[at].val += sign > 0 ? d : (0u - d);
+    }
   }
 }
 

@@ -859,6 +859,12 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   D.count_cap = fuse ? cap_u : 0; D.PB = PB; D.homecnt = pre.homecnt; D.sumA = pre.sumA; D.sumN = pre.sumN;
   D.T = t->cur; D.seed = t->seed; D.table_empty = t->lsize == 0 ? 1 : 0; D.mode = mode == INS_PLUS ? KH_DEDUP_PLUS : KH_DEDUP_FIRST; D.flags = flags;
   D.xcd_group = 0;
+  // Reducer = std::plus into a non-empty table: k_dedup only LISTS the sums of the keys the table already holds; they are added
+  // (k_apply_plus) once nothing can discard this attempt any more -- a histogram-free partition that overflowed repeats the whole
+  // batch, and a repeatable streamed insert promises "table unchanged" with KH_ERR_RETRY
+  const bool plus_live = mode == INS_PLUS && t->lsize > 0;
+  D.cnt_upd = nullptr;
+  if (plus_live) TAKE(D.cnt_upd, uint32_t, R.nparts);
   if (t->lsize > 0 && t->cur.cap > KH_L && !getenv("KH_DISABLE_XCD_GROUP")) {
     // partitions are cut for cap_u, the probes go to the (smaller) current table: 2^(PB - k) consecutive partitions share one of its chunks
     const uint32_t k_tab = log2u(t->cur.cap >> KH_LB);
@@ -884,6 +890,12 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   const uint64_t last_first = mode == INS_PLUS ? n - 1 : (t->hpin[1] ? t->hpin[1] - 1 : 0);
   if (reinterpret_cast<const uint32_t*>(t->hpin + 2)[KH_FLAG_INTERNAL])
     return fail(t, KH_ERR_HIP, "internal: de-duplication set overflow");
+  auto apply_plus = [&](int sign) {
+    Launch L(t, "k_apply_plus");
+    hipLaunchKernelGGL(k_apply_plus, dim3(std::min<uint32_t>(R.nparts, 4096u)), dim3(256), 0, t->stream, t->cur.s, S.merged_off, (const uint32_t*)D.cnt_upd,
+                       (const uint64_t*)D.nk, (const uint32_t*)D.nv, R.nparts, sign);
+  };
+  if (plus_live) apply_plus(+1);
   const uint64_t new_cap = forced_cap ? forced_cap : capacity_after(t, t->cur.cap, t->lsize, n, dnew, last_first);
   if (dnew > 0 || new_cap != t->cur.cap) {
     // a chunk of the new table owns 2^(PB-k) consecutive partitions; read their lists in place when that is a
@@ -902,7 +914,10 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     }
     const bool pre_ok = fuse && new_cap == cap_u && !reinterpret_cast<const uint32_t*>(t->hpin + 2)[KH_FLAG_FUSE_INVALID];
     st = rebuild(t, new_cap, ck, cv, lo, lc, PB, false, t->lsize + dnew, pre_ok ? &pre : nullptr);
-    if (st != KH_OK) return st;
+    if (st != KH_OK) {        // the table keeps its layout: it must keep its values too
+      if (plus_live) { apply_plus(-1); hipStreamSynchronize(t->stream); }
+      return st;
+    }
     t->lsize += dnew;
   }
   if (mode == INS_UPDATE) {   // update(k,v): existing keys take the value of their LAST occurrence in the batch
@@ -1067,8 +1082,14 @@ kh_status insert_inplace(kh_table* t, const char* kb, uint32_t kstride, const ch
   TAKE(zpre, char, 64);
   HIPCHK(hipMemsetAsync(zpre, 0, 64, t->stream));
   D.max_idx_plus1 = reinterpret_cast<unsigned long long*>(zpre); D.flags = reinterpret_cast<uint32_t*>(zpre + 32);
+  if (mode == INS_PLUS) TAKE(D.cnt_upd, uint32_t, R.nparts);
   { Launch L(t, "k_dedup");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
+  if (mode == INS_PLUS) {      // sums of the keys the table already holds (listed by k_dedup; nothing can discard an in-place batch)
+    Launch L(t, "k_apply_plus");
+    hipLaunchKernelGGL(k_apply_plus, dim3(std::min<uint32_t>(R.nparts, 4096u)), dim3(256), 0, t->stream, t->cur.s, (const uint64_t*)R.part_off, (const uint32_t*)D.cnt_upd,
+                       (const uint64_t*)D.nk, (const uint32_t*)D.nv, R.nparts, 1);
+  }
   IpResult* res = nullptr;
   st = inplace_passes<KH_IP_INSERT>(t, src, n, &res);
   if (st != KH_OK) return st;
@@ -1596,6 +1617,19 @@ kh_status kh_insert_end(kh_table* t, uint64_t* n_inserted) {
   return st;
 }
 
+kh_status kh_insert_abort(kh_table* t) {
+  if (!t) return KH_ERR_INVALID;
+  if (!t->ins.active) return KH_OK;
+  // the feeds only wrote workspace (partition records); the table itself has not been touched.  Kernels queued by the feeds may
+  // still read the caller's device buffers: wait for them, like kh_insert_end would have
+  hipSetDevice(t->device);
+  hipError_t e = hipStreamSynchronize(t->stream);
+  t->ins.active = false;
+  t->part_overflow = nullptr; t->batch_nodup = false;
+  if (e != hipSuccess) return fail(t, KH_ERR_HIP, std::string("kh_insert_abort: ") + hipGetErrorString(e));
+  return KH_OK;
+}
+
 kh_status kh_insert_reduce_plus(kh_table* t, const void* keys, const void* vals, uint64_t n, kh_mem where, uint64_t* n_inserted) {
   if (!t) return KH_ERR_INVALID;
   return do_insert(t, keys, 8, vals, 4, n, where, INS_PLUS, n_inserted);
@@ -1890,6 +1924,31 @@ kh_status kh_shard_plan_permute(kh_shard_plan* P, uint32_t piece, const uint64_t
   KH_SWITCH_HASH(P->hash, hipLaunchKernelGGL((k_shard_scatter8<HASH>), dim3(t1 - t0), dim3(KH_SHARD_THREADS), 0, stream, keys + b0, vals ? vals + b0 : nullptr, b1 - b0,
                                              P->seed, P->p, P->pmask, (const uint64_t*)P->toff, P->ntiles, out_keys, out_vals, t0, adj));
   HIPCHK(hipGetLastError());
+  return KH_OK;
+}
+// piece `piece` written to its place in the layout of the WHOLE batch grouped by rank (what kh_shard_permute of all n pairs gives):
+// the scanned [rank][tile] offsets already are positions in that layout
+kh_status kh_shard_plan_permute_global(kh_shard_plan* P, uint32_t piece, const uint64_t* keys, const uint32_t* vals, uint64_t* out_keys, uint32_t* out_vals,
+                                       void* stream_) {
+  kh_table* t = nullptr;
+  if (!P || piece >= P->pieces || (vals && !out_vals)) return KH_ERR_INVALID;
+  if (P->n == 0) return KH_OK;
+  if (!keys || !out_keys) return KH_ERR_INVALID;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  HIPCHK(hipSetDevice(P->device));
+  const uint32_t t0 = (uint32_t)((uint64_t)P->ntiles * piece / P->pieces), t1 = (uint32_t)((uint64_t)P->ntiles * (piece + 1) / P->pieces);
+  if (t1 == t0) return KH_OK;
+  const uint64_t b0 = (uint64_t)t0 * KH_SHARD_TILE, b1 = std::min<uint64_t>(P->n, (uint64_t)t1 * KH_SHARD_TILE);
+  KhShardAdj adj;      // (all zero)
+  KH_SWITCH_HASH(P->hash, hipLaunchKernelGGL((k_shard_scatter8<HASH>), dim3(t1 - t0), dim3(KH_SHARD_THREADS), 0, stream, keys + b0, vals ? vals + b0 : nullptr, b1 - b0,
+                                             P->seed, P->p, P->pmask, (const uint64_t*)P->toff, P->ntiles, out_keys, out_vals, t0, adj));
+  HIPCHK(hipGetLastError());
+  return KH_OK;
+}
+kh_status kh_shard_plan_offsets(const kh_shard_plan* P, uint64_t* out) {
+  if (!P || !out) return KH_ERR_INVALID;
+  for (size_t i = 0; i < P->bnd.size(); ++i) out[i] = P->bnd[i];
+  if (P->n == 0) for (size_t i = 0; i < P->bnd.size(); ++i) out[i] = 0;
   return KH_OK;
 }
 void kh_shard_plan_destroy(kh_shard_plan* P) {

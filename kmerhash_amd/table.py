@@ -225,6 +225,10 @@ class _HashMapBase:
         self._chk(self._L.kh_insert_end(self._h, C.byref(out)))
         return out.value
 
+    def insert_abort(self):
+        """gives up a streamed insert: the pieces fed so far are dropped, the table is unchanged and usable again"""
+        self._chk(self._L.kh_insert_abort(self._h))
+
     def insert_reduce_plus(self, keys, vals=None):
         """Reducer = std::plus (k-mer counting when vals is None: every occurrence adds 1).  Returns #new keys.
         reference: hashmap_robinhood_offsets_reduction::insert(keys, T(1)), counting_batched_robinhood_map."""

@@ -1,7 +1,11 @@
 // C++ side of the sharded map (include/kmerhash_amd_dist.h): the reference's distributed contract
 // (distributed_batched_robinhood_map.hpp:910-1194,1258,1619,2169) checked against ONE table that receives the same pairs in the
 // order the shards receive them (piece, source rank, position) -- first value wins across ranks.
-//   part 1: one RCCL rank (communicator bootstrap through khd_unique_id; p = 1 owns every key)
+//   part 1: one RCCL rank (communicator bootstrap through khd_unique_id; p = 1 owns every key), then the same rank with
+//           KHD_OPT_FORCE_COLLECTIVES: every RCCL call of the library (ncclAllToAll of the counts, grouped ncclAllToAllv per piece,
+//           ncclAllReduce votes) runs as a self-exchange and must give the unsharded table's results
+//   part 3: a rank that fails locally (khd_debug_fail_next) at each stage of insert / find / erase: no rank hangs, every rank
+//           reports, the maps stay usable;  part 4: pipelined queries (KHD_OPT_QUERY_PIECES) equal the one-piece form
 //   part 2: p = 4 and p = 3 ranks as threads of this process on one device (khd_create_local): the sharding / exchange /
 //           pipelined streamed insert code of the product over the in-process transport (RCCL refuses two ranks on one GPU)
 #include <hip/hip_runtime_api.h>
@@ -11,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -92,9 +97,9 @@ static void local_group(int P, int pieces, size_t n_per_rank, int keymode = 0) {
       OK(khd_size(m, &gsize[r]));
       const size_t nq = q[r].size();
       uint64_t* ok = dev(std::vector<uint64_t>(nq)); uint8_t* oc = dev(std::vector<uint8_t>(nq)); uint32_t* ov = dev(std::vector<uint32_t>(nq)); uint8_t* of = dev(std::vector<uint8_t>(nq));
-      OK(khd_count(m, dq, nq, ok, oc));
+      OK(khd_count(m, dq, nq, ok, oc)); OK(khd_synchronize(m));       // (count / find only queue their work)
       ck_out[r] = host(ok, nq); c_out[r] = host(oc, nq);
-      OK(khd_find(m, dq, nq, ok, ov, of));
+      OK(khd_find(m, dq, nq, ok, ov, of)); OK(khd_synchronize(m));
       fk_out[r] = host(ok, nq); v_out[r] = host(ov, nq); f_out[r] = host(of, nq);
       OK(khd_erase(m, dq, nq, &erased[r]));
       OK(khd_size(m, &gsize2[r]));
@@ -163,7 +168,157 @@ static void local_group(int P, int pieces, size_t n_per_rank, int keymode = 0) {
   std::printf("local group p=%d pieces=%d ok (%zu pairs per rank, %zu distinct)\n", P, pieces, n_per_rank, gold.size());
 }
 
-int main() {
+// ---- part 3: local failures must reach every rank, and nobody may hang -------------------------------------------------------------
+static void failure_votes(int P) {
+  std::vector<khd_map*> maps(P);
+  OK(khd_create_local(maps.data(), P, 0, KH_KIND_ROBINHOOD, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, KH_HASH_MURMUR3_X86_128_LO64, KHD_DIST_SEED));
+  const size_t n = 50000;
+  std::vector<std::vector<uint64_t> > keys(P); std::vector<std::vector<uint32_t> > vals(P);
+  for (int r = 0; r < P; ++r) for (size_t i = 0; i < n; ++i) { uint64_t d = (uint64_t(r + 1) << 40) + i; keys[r].push_back(splitmix(d)); vals[r].push_back(uint32_t(i)); }
+  // every scenario: rank `bad` fails at `stage` of operation `op` (0 insert, 1 find, 2 erase); st[r] = what rank r got back
+  auto run = [&](int op, int stage, int bad, std::vector<kh_status>& st, std::vector<kh_status>& late) {
+    st.assign(P, KH_OK); late.assign(P, KH_OK);
+    std::vector<std::thread> th;
+    for (int r = 0; r < P; ++r)
+      th.emplace_back([&, r] {
+        CHECK(hipSetDevice(0) == hipSuccess);
+        khd_map* m = maps[r];
+        uint64_t* dk = dev(keys[r]); uint32_t* dv = dev(vals[r]);
+        uint64_t* ok = dev(std::vector<uint64_t>(n)); uint32_t* ov = dev(std::vector<uint32_t>(n)); uint8_t* of = dev(std::vector<uint8_t>(n));
+        if (r == bad && stage) OK(khd_debug_fail_next(m, stage));
+        uint64_t x = 0;
+        if (op == 0) st[r] = khd_insert(m, dk, dv, n, 3, 0, &x);
+        else if (op == 1) { st[r] = khd_find(m, dk, n, ok, ov, of); late[r] = khd_synchronize(m); }
+        else st[r] = khd_erase(m, dk, 1000, &x);
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        hipFree(dk); hipFree(dv); hipFree(ok); hipFree(ov); hipFree(of);
+      });
+    for (auto& t : th) t.join();
+  };
+  std::vector<kh_status> st, late;
+  auto global_size = [&]() {
+    std::vector<uint64_t> sz(P); std::vector<std::thread> th;
+    for (int r = 0; r < P; ++r) th.emplace_back([&, r] { CHECK(hipSetDevice(0) == hipSuccess); OK(khd_size(maps[r], &sz[r])); });
+    for (auto& t : th) t.join();
+    for (int r = 1; r < P; ++r) CHECK(sz[r] == sz[0]);
+    return sz[0];
+  };
+  uint64_t expect = 0;
+  for (int stage = 1; stage <= 4; ++stage) {          // insert: all four stages; every rank must report, none may hang
+    for (int r = 0; r < P; ++r) for (size_t i = 0; i < n; ++i) { uint64_t d = (uint64_t(stage) << 50) + (uint64_t(r + 1) << 40) + i; keys[r][i] = splitmix(d); }      // fresh keys
+    uint64_t own_before = 0; OK(kh_size(khd_local(maps[1]), &own_before));
+    run(0, stage, 1, st, late);
+    for (int r = 0; r < P; ++r) CHECK(st[r] != KH_OK);
+    CHECK(st[1] == KH_ERR_NOMEM);
+    CHECK(std::strstr(khd_last_error(maps[1]), "injected") && std::strstr(khd_last_error(maps[0]), "peer rank failed"));
+    // the maps stay usable (a collective size).  Stages 1 to 3 fail before any rank builds: nothing inserted anywhere; 4: the
+    // healthy ranks hold their share, the failing rank's table is unchanged
+    const uint64_t gs = global_size();
+    uint64_t own_after = 0; OK(kh_size(khd_local(maps[1]), &own_after));
+    CHECK(own_after == own_before);
+    if (stage <= 3) CHECK(gs == expect); else CHECK(gs > expect && gs < expect + (uint64_t)P * n);
+    run(0, 0, -1, st, late);                            // the same pairs again, nobody fails: first value wins, everything is in
+    for (int r = 0; r < P; ++r) CHECK(st[r] == KH_OK);
+    expect += (uint64_t)P * n;
+    CHECK(global_size() == expect);
+  }
+  for (int stage = 1; stage <= 3; ++stage) {          // find: stages 1 and 2 are voted at once; stage 3 is reported late to the peers
+    run(1, stage, 2 % P, st, late);
+    const int bad = 2 % P;
+    CHECK(st[bad] == KH_ERR_NOMEM);
+    for (int r = 0; r < P; ++r) {
+      if (stage <= 2) CHECK(st[r] != KH_OK);
+      else if (r != bad) { CHECK(st[r] == KH_OK); CHECK(late[r] == KH_ERR_NOMEM); }
+    }
+    run(1, 0, -1, st, late);
+    for (int r = 0; r < P; ++r) CHECK(st[r] == KH_OK && late[r] == KH_OK);
+  }
+  for (int stage = 1; stage <= 4; ++stage) {          // erase: nothing is erased anywhere unless every rank sent its real keys (stages 1-3)
+    const uint64_t before = global_size();
+    run(2, stage, 0, st, late);
+    for (int r = 0; r < P; ++r) CHECK(st[r] != KH_OK);
+    CHECK(st[0] == KH_ERR_NOMEM);
+    const uint64_t after = global_size();
+    if (stage <= 3) CHECK(after == before); else CHECK(after < before);
+  }
+  run(2, 0, -1, st, late);
+  for (int r = 0; r < P; ++r) CHECK(st[r] == KH_OK);
+  for (int r = 0; r < P; ++r) OK(khd_destroy(maps[r]));
+  std::printf("failure votes p=%d ok (insert stages 1-4, find 1-3, erase 1-3: every rank reported, none hung, maps reusable)\n", P);
+}
+
+// a rank that never arrives: its peers give up after KHD_OPT_TIMEOUT_MS instead of waiting for ever, and their map is finished
+static void absent_peer() {
+  const int P = 2;
+  std::vector<khd_map*> maps(P);
+  OK(khd_create_local(maps.data(), P, 0, KH_KIND_ROBINHOOD, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, KH_HASH_MURMUR3_X86_128_LO64, KHD_DIST_SEED));
+  OK(khd_set_option(maps[1], KHD_OPT_TIMEOUT_MS, 300));
+  std::vector<uint64_t> k(1000); uint64_t s = 3; for (auto& x : k) x = splitmix(s);
+  uint64_t* dk = dev(k); uint64_t x = 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  CHECK(khd_erase(maps[1], dk, k.size(), &x) == KH_ERR_HIP);          // rank 0 never calls
+  CHECK(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 20.0);
+  CHECK(std::strstr(khd_last_error(maps[1]), "never arrived"));
+  CHECK(khd_size(maps[1], &x) == KH_ERR_HIP);                         // the map is finished
+  CHECK(khd_size(maps[0], &x) == KH_ERR_HIP);                         // ... and so is its peer's: the group has been left
+  hipFree(dk);
+  for (int r = 0; r < P; ++r) OK(khd_destroy(maps[r]));
+  std::printf("absent peer: bounded wait ok\n");
+}
+
+// ---- part 4: pipelined queries ----------------------------------------------------------------------------------------------------
+static void pipelined_queries(int P, size_t nq, bool timing) {
+  std::vector<khd_map*> maps(P);
+  OK(khd_create_local(maps.data(), P, 0, KH_KIND_ROBINHOOD, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, KH_HASH_MURMUR3_X86_128_LO64, KHD_DIST_SEED));
+  std::vector<std::vector<uint64_t> > keys(P), q(P); std::vector<std::vector<uint32_t> > vals(P);
+  for (int r = 0; r < P; ++r) {
+    for (size_t i = 0; i < nq; ++i) { uint64_t d = (uint64_t(r + 1) << 40) + i; keys[r].push_back(splitmix(d)); vals[r].push_back(uint32_t(r * 100000000u + i)); }
+    uint64_t s = 17 + r;
+    for (size_t i = 0; i < nq; ++i) q[r].push_back(i % 4 ? keys[(r + i) % P][splitmix(s) % nq] : (splitmix(s) | 1ull << 63));     // other ranks' keys + misses
+  }
+  std::vector<std::vector<uint64_t> > ok1(P), okN(P); std::vector<std::vector<uint32_t> > v1(P), vN(P); std::vector<std::vector<uint8_t> > f1(P), fN(P), c1(P), cN(P);
+  std::vector<double> ms1(P), msN(P);
+  std::vector<std::thread> th;
+  for (int r = 0; r < P; ++r)
+    th.emplace_back([&, r] {
+      CHECK(hipSetDevice(0) == hipSuccess);
+      hipStream_t st; CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+      khd_map* m = maps[r];
+      OK(khd_set_stream(m, st));
+      uint64_t* dk = dev(keys[r]); uint32_t* dv = dev(vals[r]); uint64_t* dq = dev(q[r]); uint64_t x = 0;
+      OK(khd_insert(m, dk, dv, nq, 2, 0, &x));
+      uint64_t* ok = dev(std::vector<uint64_t>(nq)); uint8_t* oc = dev(std::vector<uint8_t>(nq)); uint32_t* ov = dev(std::vector<uint32_t>(nq)); uint8_t* of = dev(std::vector<uint8_t>(nq));
+      for (int pieces : {1, 4}) {
+        OK(khd_set_option(m, KHD_OPT_QUERY_PIECES, r == 1 && pieces == 4 ? 3 : pieces));      // (ranks may choose differently)
+        double best = 1e30;
+        for (int rep = 0; rep < (timing ? 4 : 1); ++rep) {
+          CHECK(hipMemset(ov, 0xEE, nq * 4) == hipSuccess);
+          uint64_t sz = 0; OK(khd_size(m, &sz));              // (collective: the ranks start together)
+          auto t0 = std::chrono::steady_clock::now();
+          OK(khd_find(m, dq, nq, ok, ov, of)); OK(khd_synchronize(m));
+          OK(khd_size(m, &sz));
+          best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        OK(khd_count(m, dq, nq, ok, oc)); OK(khd_synchronize(m));
+        if (pieces == 1) { ok1[r] = host(ok, nq); v1[r] = host(ov, nq); f1[r] = host(of, nq); c1[r] = host(oc, nq); ms1[r] = best; }
+        else { okN[r] = host(ok, nq); vN[r] = host(ov, nq); fN[r] = host(of, nq); cN[r] = host(oc, nq); msN[r] = best; }
+      }
+      hipFree(dk); hipFree(dv); hipFree(dq); hipFree(ok); hipFree(oc); hipFree(ov); hipFree(of);
+    });
+  for (auto& t : th) t.join();
+  for (int r = 0; r < P; ++r) {
+    CHECK(ok1[r] == okN[r] && f1[r] == fN[r] && c1[r] == cN[r] && c1[r] == f1[r]);        // same permuted order, same flags
+    size_t hits = 0;
+    for (size_t i = 0; i < nq; ++i) if (f1[r][i]) { CHECK(v1[r][i] == vN[r][i]); ++hits; } else CHECK(vN[r][i] == 0xEEEEEEEEu);      // a miss leaves the value untouched
+    CHECK(hits > nq / 2 && hits < nq);
+  }
+  double a = 0, b = 0; for (int r = 0; r < P; ++r) { a = std::max(a, ms1[r]); b = std::max(b, msN[r]); }
+  std::printf("pipelined queries p=%d, %zu finds per rank: 1 piece %.3f ms, 4 pieces %.3f ms (x%.2f)\n", P, nq, a, b, a / b);
+  for (int r = 0; r < P; ++r) OK(khd_destroy(maps[r]));
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && !std::strcmp(argv[1], "--query-timing")) { pipelined_queries(4, 10000000, true); return 0; }
   {  // one RCCL rank
     char id[KHD_UNIQUE_ID_BYTES];
     OK(khd_unique_id(id));
@@ -183,6 +338,56 @@ int main() {
     OK(khd_destroy(m));
     std::printf("rccl single rank ok\n");
   }
+  {  // one RCCL rank, every collective executed (self-exchange): must equal the unsharded table fed the same pairs
+    char id[KHD_UNIQUE_ID_BYTES];
+    OK(khd_unique_id(id));
+    khd_map* m = nullptr;
+    OK(khd_create(&m, id, 1, 0, 0, KH_KIND_ROBINHOOD, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, KH_HASH_MURMUR3_X86_128_LO64, KHD_DIST_SEED));
+    OK(khd_set_option(m, KHD_OPT_FORCE_COLLECTIVES, 1));
+    OK(khd_set_option(m, KHD_OPT_QUERY_PIECES, 3));
+    kh_table* plain = nullptr;
+    OK(kh_create(&plain, KH_KIND_ROBINHOOD, 8, 4, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, 0));
+    const size_t n = 3000000;       // (>= 2^20 pairs per piece at 2^10 partitions: the repeatable streamed insert's histogram-free layout)
+    std::vector<uint64_t> k(n); std::vector<uint32_t> v(n);
+    uint64_t s = 11; for (size_t i = 0; i < n; ++i) { k[i] = splitmix(s); v[i] = uint32_t(i); }
+    for (size_t i = 0; i < 5000; ++i) k[n - 1 - i] = k[i * 7];          // duplicates the first piece's sample cannot see: the retry path over RCCL
+    uint64_t* dk = dev(k); uint32_t* dv = dev(v); uint64_t ni = 0, np_ = 0, gs = 0, ne = 0, nep = 0;
+    OK(khd_insert(m, dk, dv, n, 4, 0, &ni));
+    OK(kh_insert(plain, dk, dv, n, KH_MEM_DEVICE, &np_));
+    CHECK(ni == np_ && ni == n - 5000);
+    OK(khd_size(m, &gs)); CHECK(gs == ni);                                 // ncclAllReduce(sum)
+    CHECK(contents(khd_local(m)) == contents(plain));
+    { uint64_t c1 = 0, c2 = 0; OK(kh_capacity(khd_local(m), &c1)); OK(kh_capacity(plain, &c2)); CHECK(c1 == c2);
+      std::vector<uint8_t> i1(c1), i2(c2); OK(kh_export_info(khd_local(m), i1.data())); OK(kh_export_info(plain, i2.data())); CHECK(i1 == i2); }
+    const size_t nq = 500000;
+    std::vector<uint64_t> q(nq); for (size_t i = 0; i < nq; ++i) q[i] = i % 3 ? k[splitmix(s) % n] : splitmix(s);
+    uint64_t* dq = dev(q);
+    uint64_t* ok = dev(std::vector<uint64_t>(nq)); uint32_t* ov = dev(std::vector<uint32_t>(nq, 7u)); uint8_t* of = dev(std::vector<uint8_t>(nq)); uint8_t* oc = dev(std::vector<uint8_t>(nq));
+    uint32_t* pv = dev(std::vector<uint32_t>(nq, 7u)); uint8_t* pf = dev(std::vector<uint8_t>(nq));
+    OK(khd_find(m, dq, nq, ok, ov, of)); OK(khd_count(m, dq, nq, nullptr, oc)); OK(khd_synchronize(m));
+    OK(kh_find(plain, dq, nq, KH_MEM_DEVICE, pv, pf, nullptr));
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    CHECK(host(ok, nq) == q && host(ov, nq) == host(pv, nq) && host(of, nq) == host(pf, nq) && host(oc, nq) == host(pf, nq));      // one rank: permuted order == input order
+    OK(khd_erase(m, dq, nq, &ne)); OK(kh_erase(plain, dq, nq, KH_MEM_DEVICE, &nep));
+    CHECK(ne == nep && ne > 0);
+    CHECK(contents(khd_local(m)) == contents(plain));
+    // counting insert (std::plus, no values) through the same path
+    khd_map* cm = nullptr; kh_table* cplain = nullptr;
+    OK(khd_unique_id(id));
+    OK(khd_create(&cm, id, 1, 0, 0, KH_KIND_ROBINHOOD, KH_HASH_FARM64, 43, 128, 0.35f, 0.8f, KH_HASH_MURMUR3_X86_128_LO64, KHD_DIST_SEED));
+    OK(khd_set_option(cm, KHD_OPT_FORCE_COLLECTIVES, 1));
+    OK(kh_create(&cplain, KH_KIND_ROBINHOOD, 8, 4, KH_HASH_FARM64, 43, 128, 0.35f, 0.8f, 0));
+    OK(khd_insert(cm, dk, nullptr, n, 3, 1, &ni)); OK(kh_insert_reduce_plus(cplain, dk, nullptr, n, KH_MEM_DEVICE, &np_));
+    CHECK(ni == np_ && contents(khd_local(cm)) == contents(cplain));
+    char buf[512]; OK(khd_phase_ms(m, buf, sizeof(buf)));
+    CHECK(std::strstr(buf, "exchange") && std::strstr(buf, "permute") && std::strstr(buf, "refeed"));
+    OK(khd_destroy(m)); OK(khd_destroy(cm)); OK(kh_destroy(plain)); OK(kh_destroy(cplain));
+    hipFree(dk); hipFree(dv); hipFree(dq); hipFree(ok); hipFree(ov); hipFree(of); hipFree(oc); hipFree(pv); hipFree(pf);
+    std::printf("rccl single rank, forced collectives ok (ncclAllToAll counts, grouped ncclAllToAllv x4 pieces + retry, ncclAllReduce votes, pipelined find/count, erase)\n");
+  }
+  failure_votes(3);
+  absent_peer();
+  pipelined_queries(3, 300000, false);
   local_group(4, 3, 60000);
   local_group(3, 1, 20000);      // rank = hash % p (not a power of two), one exchange then one bulk insert
   local_group(2, 5, 300000);

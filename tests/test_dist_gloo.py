@@ -52,6 +52,9 @@ class OracleBackend:
             def insert_feed(s, k, v=None):
                 s._feed.append((k.clone(), v.clone() if v is not None else None))
 
+            def insert_abort(s):
+                s._feed = []
+
             def insert_end(s):
                 # force_retry: this repeatable streamed insert "fails its speculation" (like kh_insert_end returning KH_ERR_RETRY):
                 # the sharded layer must feed the pieces it kept again, without the flag
@@ -118,7 +121,7 @@ def _worker(rank, world, port, q):
         tk = torch.from_numpy(keys.view(np.int64).copy())
         tv = torch.from_numpy(vals.view(np.int32).copy())
         st.insert(tk, tv)
-        assert st.collectives == {"counts": 1, "payload": 1}, st.collectives       # keys and values travel in ONE grouped exchange
+        assert st.collectives == {"counts": 1, "payload": 1, "votes": 3}, st.collectives       # keys and values travel in ONE grouped exchange
         # single-table model: receive order is (source rank 0..p-1, then position)
         allk = [None] * world
         allv = [None] * world
@@ -140,13 +143,13 @@ def _worker(rank, world, port, q):
         qk = np.concatenate([keys[:5000], W.distinct_u64(5000, seed=55 + rank)])
         c0 = dict(st.collectives)
         pk, cnt = st.count(torch.from_numpy(qk.view(np.int64).copy()))
-        assert st.collectives == {"counts": c0["counts"] + 1, "payload": c0["payload"] + 2}
+        assert st.collectives == {"counts": c0["counts"] + 1, "payload": c0["payload"] + 2, "votes": c0["votes"] + 1}
         universe = set(np.concatenate(allk).tolist())
         exp = np.array([1 if int(k) in universe else 0 for k in pk.numpy().view(np.uint64)], dtype=np.uint8)
         assert np.array_equal(cnt.numpy(), exp)
         c0 = dict(st.collectives)
         pk2, fv, ff = st.find(torch.from_numpy(qk.view(np.int64).copy()))
-        assert st.collectives == {"counts": c0["counts"] + 1, "payload": c0["payload"] + 2}, st.collectives   # keys out, (values, flags) back
+        assert st.collectives == {"counts": c0["counts"] + 1, "payload": c0["payload"] + 2, "votes": c0["votes"] + 1}, st.collectives   # keys out, (values, flags, status) back
         assert np.array_equal(ff.numpy(), exp)
         # first-wins across ranks: the value of a duplicated key is the one from the lowest source rank
         first = {}
@@ -162,7 +165,7 @@ def _worker(rank, world, port, q):
         chunks = 3
         sp = ShardedTable(OracleBackend(O, O.KIND_RH), timing=True)
         sp.insert(tk, tv, chunks=chunks)
-        assert sp.collectives == {"counts": 1, "payload": chunks}, sp.collectives
+        assert sp.collectives == {"counts": 1, "payload": chunks, "votes": 3}, sp.collectives
         assert set(sp.timings()) >= {"count_pass", "permute", "exchange", "feed", "build"}
         bnd = [n * i // chunks for i in range(chunks + 1)]
         model_p = O.OracleTable(O.KIND_RH, 128, 0.35, 0.8, O.HASH_MURMUR3_X86, 43)
@@ -198,6 +201,43 @@ def _worker(rank, world, port, q):
         both = np.unique(np.concatenate([a[:1000] for a in allk]))
         assert int(tot.item()) == len(both)
         assert st.size() == gsize - len(both)
+        # ---- a rank that fails locally: every rank raises (the failing one its own error, the others ShardPeerError), nobody hangs in
+        #      a collective, the tables stay usable.  insert: stages 1-4; find: 1-3; erase: 1-3
+        import time
+        from kmerhash_amd.dist import ShardPeerError
+        bad = world - 1
+        for op, stages in (("insert", (1, 2, 3, 4)), ("find", (1, 2, 3)), ("erase", (1, 2, 3, 4))):
+            for stage in stages:
+                sf = ShardedTable(OracleBackend(O, O.KIND_RH))
+                if op != "insert":
+                    sf.insert(tk, tv, chunks=2)
+                if rank == bad:
+                    sf._fail_stage = stage
+                t0 = time.time()
+                try:
+                    if op == "insert":
+                        sf.insert(tk, tv, chunks=3)
+                    elif op == "find":
+                        sf.find(tk[:4000])
+                    else:
+                        sf.erase(tk[:4000])
+                    raised = None
+                except MemoryError as e:
+                    raised = "own"
+                except ShardPeerError as e:
+                    raised = "peer"
+                assert raised == ("own" if rank == bad else "peer"), (op, stage, rank, raised)
+                assert time.time() - t0 < 60
+                # usable afterwards: the same call again, nobody fails
+                if op == "insert":
+                    sf.insert(tk, tv, chunks=3)
+                    assert sf.size() == gsize
+                elif op == "find":
+                    _, _, ff2 = sf.find(tk[:4000])
+                    assert int(ff2.sum()) == 4000
+                else:
+                    sf.erase(tk[:4000])
+                    assert sf.size() == gsize - len(np.unique(np.concatenate([a[:4000] for a in allk])))
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
