@@ -1146,3 +1146,101 @@ def test_histogram_free_partition_and_its_fall_backs(oracle):
             assert "k_part_hist" in p and p["k_part_scatter"][0] == 4, p       # histogram-free attempt, then exact
         check_state(g, o, 0)
         g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+def test_reducer_plus_speculation_never_touches_live_counts(kname, cls, kind):
+    """ADVICE r2 (high): a Reducer = std::plus insert into a NON-EMPTY table whose histogram-free partition overflows a slot (hidden
+    skew) is repeated with exact offsets -- the counts of the keys the table already holds must be added ONCE.  k_dedup only lists
+    those sums; k_apply_plus adds them after the overflow flag has been read.  One-shot form, then the repeatable streamed form:
+    KhRetry must leave the table exactly as it was (kmerhash_amd.h: 'table unchanged'), and the plain re-feed gives numpy's sums."""
+    n = 4_000_000
+    base = W.distinct_u64(1000, seed=3)
+    fresh = W.distinct_u64(n, seed=4)
+    k = fresh.copy()
+    k[(n // 65536) * np.arange(30_000) + 1] = fresh[7]              # one key 30000 times, between the sample's positions
+    k[(n // 65536) * np.arange(40_000, 40_600) + 2] = base[:600]      # keys the table already holds (counts must grow by exactly 1)
+    k[(n // 65536) * np.arange(41_000, 41_100) + 2] = base[:100]      # ... some of them twice
+
+    def expected(pre_k, pre_c, batch):
+        uk, cnt = np.unique(np.concatenate([np.repeat(pre_k, pre_c.astype(np.int64)), batch]), return_counts=True)
+        return uk, cnt.astype(np.uint32)
+
+    # one-shot
+    g = cls(128, 0.35, 0.8)
+    g.insert_reduce_plus(dev(base))
+    g.insert_reduce_plus(dev(base[:10]))                              # counts 2 for ten of them
+    pk, pc = g.sorted_items()
+    g.profile_enable(True)
+    g.insert_reduce_plus(dev(k))
+    p = g.profile()
+    assert p["k_part_scatter"][0] == 4 and "k_apply_plus" in p, p      # histogram-free attempt overflowed, exact offsets after it
+    sk, sv = g.sorted_items()
+    uk, cnt = expected(pk, pc, k)
+    assert np.array_equal(sk, uk) and np.array_equal(sv, cnt)
+    g.close()
+    # repeatable streamed form: KhRetry leaves the table unchanged
+    g = cls(128, 0.35, 0.8)
+    g.insert_reduce_plus(dev(base))
+    g.insert_reduce_plus(dev(base[:10]))
+    before = g.sorted_items(), g.capacity(), g.export_info().copy()
+    cuts = [0, 1_500_000, 2_500_000, n]
+
+    def feed_all(**kw):
+        g.insert_begin(n, reduce_plus=True, **kw)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            g.insert_feed(dev(k[a:b]))
+        return g.insert_end()
+
+    with pytest.raises(kh.KhRetry):
+        feed_all(repeatable=True)
+    after = g.sorted_items(), g.capacity(), g.export_info()
+    assert np.array_equal(before[0][0], after[0][0]) and np.array_equal(before[0][1], after[0][1]) and before[1] == after[1]
+    assert np.array_equal(before[2], after[2])
+    feed_all()
+    sk, sv = g.sorted_items()
+    assert np.array_equal(sk, uk) and np.array_equal(sv, cnt)
+    # an aborted streamed insert leaves the table unchanged and usable
+    g.insert_begin(1000, reduce_plus=True)
+    g.insert_feed(dev(base[:500]))
+    g.insert_abort()
+    sk2, sv2 = g.sorted_items()
+    assert np.array_equal(sk2, uk) and np.array_equal(sv2, cnt)
+    g.insert_reduce_plus(dev(base[:5]))
+    assert g.size() == len(uk)
+    g.close()
+
+
+def _fmix64(k):
+    k = k.astype(np.uint64).copy()
+    k ^= k >> np.uint64(33); k *= np.uint64(0xff51afd7ed558ccd); k ^= k >> np.uint64(33); k *= np.uint64(0xc4ceb9fe1a85ec53); k ^= k >> np.uint64(33)
+    return k
+
+
+def test_reducer_plus_class_restart_counts_once():
+    """the in-kernel half of the same finding: a partition with more distinct keys than one LDS pass holds (1536) is swept in R classes
+    (class = fmix64(key + c) >> 32 mod R), and a class that overflows restarts the sweep with 2R classes.  Sums of existing keys listed
+    by the abandoned sweep must not be applied.  Crafted: a mid-size batch (in-place path, 4 partitions) whose 3400 keys all fall into
+    partition 0, 900 of them in class 0 of R = 2 (fits: its sums were added by the old code) and 2500 in class 1 (overflows ->
+    R = 4, everything again).  All keys exist already: every one is an update."""
+    n0 = 2_000_000
+    uni = W.distinct_u64(n0, seed=31)
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    g.insert_reduce_plus(dev(uni))
+    assert g.capacity() == 1 << 22
+    h = kh.hash_batch(uni[:400_000], "murmur3avx64", 43)
+    part0 = ((h >> np.uint64(11)) & np.uint64(3)) == 0                 # PB = 2: partition = bit-reversed low 2 bits of the chunk id; 0 stays 0
+    cls1 = ((_fmix64(uni[:400_000] + np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)) % np.uint64(2)) == 1
+    c0 = uni[:400_000][part0 & ~cls1][:900]
+    c1 = uni[:400_000][part0 & cls1][:2500]
+    assert len(c0) == 900 and len(c1) == 2500
+    batch = np.concatenate([c0, c1, c0[:300]])                           # (some twice)
+    batch = batch[W.shuffle_perm(len(batch), 1)]
+    g.profile_enable(True)
+    assert g.insert_reduce_plus(dev(batch)) == 0
+    p = g.profile()
+    assert "k_part_direct" in p and "k_apply_plus" in p, p               # the in-place path of mid-size batches
+    sk, sv = g.sorted_items()
+    uk, cnt = np.unique(np.concatenate([uni, batch]), return_counts=True)
+    assert np.array_equal(sk, uk) and np.array_equal(sv, cnt.astype(np.uint32))
+    g.close()
