@@ -119,6 +119,28 @@ def _cpu_sharded(keys, vals, q, P):
                       "one process each, common start (the reference's MPI model without the exchange)" % (len(keys), len(q), P, P)}
 
 
+def host_cores():
+    """physical cores of the host (distinct (physical id, core id) pairs of /proc/cpuinfo), logical CPUs, and the CPUs this process may
+    run on (SURVEY 8d-ii asks for the physical count next to the sharded figure)"""
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+        if pid is not None and cid is not None:
+            phys.add((pid, cid))
+    except Exception:
+        pass
+    return {"physical": len(phys) or None, "logical": os.cpu_count(), "affinity": len(os.sched_getaffinity(0))}
+
+
 def cpu_baseline(keys, vals, q):
     """the CPU oracle (own restatement of the reference RH table: kind 'port') timed on the host cores, on a bounded
     sample of the same stream.  value: ONE thread (the reference is single-threaded per rank: the benchmark_hashtables
@@ -149,13 +171,222 @@ def cpu_baseline(keys, vals, q):
             del r
     except Exception as e:
         out["reference_lp"] = {"error": repr(e)}
+    out["host_cores"] = host_cores()
     try:
         P = max(1, min(len(os.sched_getaffinity(0)), 16))       # the GPU box's CPU share for one GPU is 16 cores
         if P > 1:
             ns, nqs = min(len(keys), 2 * n), min(len(q), 2 * nq)    # the ranks run in parallel: a larger sample fits the time budget
             out["sharded"] = _cpu_sharded(keys[:ns], vals[:ns], q[:nqs], P)
+            out["sharded"]["host_physical_cores"] = out["host_cores"]["physical"]
+            out["sharded"]["cores_note"] = "P = min(CPUs this process may run on, 16: one GPU's share of the box); the host has %s physical cores" % out["host_cores"]["physical"]
     except Exception as e:                    # the single-thread figure stands on its own
         out["sharded"] = {"error": repr(e)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY 8d timing protocol beyond the headline (N == 1, after the timed region; informational keys of the JSON line)
+# ---------------------------------------------------------------------------------------------------------------------
+B_COUNT, B_ERASE = 26, 42          # SURVEY 8d algorithmic bytes: count 8 + 17 + 1, erase (hit) 8 + 17 + 17
+
+
+def _srl(x, s):
+    """logical right shift of an int64 tensor"""
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _splitmix64_t(x):
+    """workloads.splitmix64 on an int64 CUDA tensor (wrapping arithmetic; bit-identical to the numpy generator)"""
+    import torch
+    c = lambda v: torch.tensor(np.array([v], dtype=np.uint64).view(np.int64)[0], dtype=torch.int64, device=x.device)
+    z = x + c(0x9E3779B97F4A7C15)
+    z = (z ^ _srl(z, 30)) * c(0xBF58476D1CE4E5B9)
+    z = (z ^ _srl(z, 27)) * c(0x94D049BB133111EB)
+    return z ^ _srl(z, 31)
+
+
+def gpu_w1(n_pairs, dev, seed=23, repeats=10):
+    """W1 on the device: the benchmark_hashtables shape (BenchmarkHashTables.cpp:192-223): a 62-bit key, then `draw % 10` more copies,
+    values = running index, shuffled.  Same rule as workloads.w1_benchmark_hashtables (the permutation is torch's)."""
+    import torch
+    est = int(n_pairs / ((repeats + 1) / 2.0) * 1.1) + 16
+    idx = torch.arange(1, est + 1, dtype=torch.int64, device=dev)
+    base = _splitmix64_t(idx + (seed << 40)) & ((1 << 62) - 1)
+    freq = (_srl(_splitmix64_t(idx + ((seed + 1) << 40)), 1) % repeats) + 1
+    keys = torch.repeat_interleave(base, freq)[:n_pairs]
+    assert keys.numel() == n_pairs
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    p = torch.randperm(n_pairs, device=dev, generator=g)
+    return keys[p].contiguous(), p.to(torch.int32).contiguous()
+
+
+def gpu_w3(n_distinct, dev, mult=5, seed=3):
+    """W3 on the device: n_distinct distinct 62-bit keys (2-bit packed 31-mers), each exactly `mult` times, shuffled"""
+    import torch
+    c = lambda v: torch.tensor(np.array([v], dtype=np.uint64).view(np.int64)[0], dtype=torch.int64, device=dev)
+    m62 = (1 << 62) - 1
+    ctr = torch.arange(n_distinct, dtype=torch.int64, device=dev) + seed * 1000003
+    base = (ctr * c(0x9E3779B97F4A7C15)) & m62          # bijections on 62 bits: odd multiplier, xorshift
+    base = base ^ (base >> 31)
+    base = (base * c(0xBF58476D1CE4E5B9)) & m62
+    base = base ^ (base >> 29)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    p = torch.randperm(n_distinct * mult, device=dev, generator=g)
+    keys = base.repeat_interleave(mult)[p].contiguous()
+    return base, keys, p.to(torch.int32).contiguous()
+
+
+def _stat(ms, ops, bytes_per_op):
+    ms = sorted(ms)
+    med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+    rate = ops / (med * 1e-3)
+    return {"ms_median": round(med, 4), "ms_min": round(ms[0], 4), "ops": int(ops), "ops_per_s": rate, "bytes_per_op": bytes_per_op,
+            "frac": rate * bytes_per_op / 1e9 / HBM_PEAK_GBS}
+
+
+def five_phases(cls, keys, vals, q_hit, q_miss, n_distinct, host, repeats, hash_name):
+    """insert, find, find_miss, count, erase, count2 (BenchmarkHashTables.cpp:1037-1186) on a fresh table per repeat; 1 warm-up.
+    host=False: device tensors, HIP events on the stream the library works on; host=True: numpy in / numpy out, wall clock around
+    each call (H2D of the inputs and D2H of the results included -- the reference's semantics are host std::vectors)."""
+    import torch
+    names = ("insert", "find", "find_miss", "count", "erase", "count2")
+    rows = {k: [] for k in names}
+    nq = len(q_hit)
+    for rep in range(repeats + 1):
+        t = cls(128, 0.35, 0.8, hash=hash_name, seed=43)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        wall = []
+
+        def mark(i):
+            if host:
+                torch.cuda.synchronize()
+                wall.append(time.perf_counter())
+            else:
+                ev[i].record()
+
+        mark(0)
+        n_ins = t.insert(keys, vals)
+        mark(1)
+        fk, fv = t.find(q_hit)
+        mark(2)
+        mk, mv = t.find(q_miss)
+        mark(3)
+        c = t.count(q_hit)
+        mark(4)
+        n_er = t.erase(q_hit)
+        mark(5)
+        c2 = t.count(q_hit)
+        mark(6)
+        torch.cuda.synchronize()
+        # size-independent properties at full size: every distinct key once, every hit found, no miss found, erased keys gone
+        assert n_ins == n_distinct, (n_ins, n_distinct)
+        assert len(fk) == nq and len(mk) == 0 and int(c.sum()) == nq and int(c2.sum()) == 0 and n_er == nq, (len(fk), len(mk), n_er)
+        assert t.size() == n_distinct - n_er
+        t.close()
+        if rep == 0:
+            continue
+        for i, k in enumerate(names):
+            rows[k].append((wall[i + 1] - wall[i]) * 1e3 if host else ev[i].elapsed_time(ev[i + 1]))
+    n = len(keys)
+    return {"insert": _stat(rows["insert"], n, B_INSERT_NEW), "find": _stat(rows["find"], nq, B_FIND_HIT),
+            "find_miss": _stat(rows["find_miss"], len(q_miss), B_FIND_MISS), "count": _stat(rows["count"], nq, B_COUNT),
+            "erase": _stat(rows["erase"], nq, B_ERASE), "count2": _stat(rows["count2"], nq, B_FIND_MISS),
+            "repeats": repeats, "timing": "wall clock incl. H2D/D2H" if host else "HIP events, device-resident"}
+
+
+def run_extras(args, dev, keys, vals, q, dk, dv, dq):
+    """phases (RH and LP, device-resident), host_inclusive, w1, second_batch, lp_config2"""
+    import torch
+    import kmerhash_amd as kh
+    from kmerhash_amd import workloads as W
+    out = {}
+    n, nq = len(keys), len(q)
+    miss = W.distinct_u64(nq, seed=977)                       # a counter range the inserted keys do not use
+    dmiss = torch.from_numpy(miss.view(np.int64)).to(dev)
+    tables = (("robinhood", kh.hashmap_robinhood_doubling), ("linearprobe", kh.hashmap_linearprobe_doubling))
+    out["phases"] = {name: five_phases(cls, dk, dv, dq, dmiss, n, False, 5, args.hash) for name, cls in tables}
+    out["phases"]["workload"] = "%d distinct keys, %d all-hit queries / %d misses; erase = the %d queried keys; fresh table per repeat, 1 warm-up + 5 repeats" % (n, nq, nq, nq)
+    out["phases"]["bytes_per_op"] = "SURVEY 8d: insert 50, find hit 41, find miss 9, count 26, erase 42 (count2 = count of erased keys: 9); frac = ops/s x bytes / 8 TB/s"
+    out["host_inclusive"] = {name: five_phases(cls, keys, vals, q, miss, n, True, 2, args.hash) for name, cls in tables}
+    out["host_inclusive"]["workload"] = "the same phases with numpy arrays in and out (pageable host memory): H2D of keys/values/queries and D2H of the results are inside the timed calls"
+    torch.cuda.empty_cache()
+    # ---- W1: the reference benchmark's own input shape (x5.5 mean multiplicity): 10^8 pairs, 10^7 all-hit queries
+    n1 = 100_000_000
+    k1, v1 = gpu_w1(n1, dev)
+    q1 = k1[:nq].contiguous()
+    d1 = int(torch.unique(k1).numel())
+    ms = {"insert": [], "find": [], "count": [], "erase": []}
+    for rep in range(4):
+        t = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=args.hash, seed=43)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record(); ni = t.insert(k1, v1)
+        ev[1].record(); fk, fv = t.find(q1)
+        ev[2].record(); c = t.count(q1)
+        ev[3].record(); ne = t.erase(q1)
+        ev[4].record(); torch.cuda.synchronize()
+        assert ni == d1 and fk.numel() == nq and int(c.sum().item()) == nq and t.size() == d1 - ne
+        cap1 = t.capacity()
+        t.close()
+        if rep:
+            for i, k in enumerate(("insert", "find", "count", "erase")):
+                ms[k].append(ev[i].elapsed_time(ev[i + 1]))
+    dup = n1 - d1
+    out["w1"] = {"workload": "benchmark_hashtables shape (BenchmarkHashTables.cpp:192-223): %d pairs, %d distinct 62-bit keys (mean multiplicity %.2f), capacity %d, %d all-hit queries"
+                             % (n1, d1, n1 / d1, cap1, nq),
+                 "insert": _stat(ms["insert"], n1, (d1 * B_INSERT_NEW + dup * B_INSERT_DUP) / n1), "find": _stat(ms["find"], nq, B_FIND_HIT),
+                 "count": _stat(ms["count"], nq, B_COUNT), "erase": _stat(ms["erase"], nq, B_ERASE)}
+    del k1, v1, q1
+    torch.cuda.empty_cache()
+    # ---- second batch into the loaded table (k_build_fused SRC 2): 2*10^7 new keys + 10^6 repeats of inserted ones
+    extra_k = torch.from_numpy(W.distinct_u64(20_000_000, seed=7).view(np.int64)).to(dev)
+    b2 = torch.cat([extra_k, dk[:1_000_000]])
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    b2 = b2[torch.randperm(b2.numel(), device=dev, generator=g)].contiguous()
+    v2 = torch.arange(b2.numel(), dtype=torch.int32, device=dev)
+    n_first = 80_000_000                                  # 8*10^7 + 2*10^7 = 10^8 <= max_load(2^27): no doubling, the in-capacity form
+    ms2, fused = [], 0
+    for rep in range(4):
+        t = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=args.hash, seed=43)
+        t.insert(dk[:n_first], dv[:n_first])
+        t.profile_enable(True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ni = t.insert(b2, v2); e1.record(); torch.cuda.synchronize()
+        assert ni == 20_000_000 and t.size() == n_first + 20_000_000, (ni, t.size())
+        fused += 1 if "k_insert_fused" in t.profile() else 0
+        cap2 = t.capacity()
+        t.close()
+        if rep:
+            ms2.append(e0.elapsed_time(e1))
+    out["second_batch"] = dict(_stat(ms2, b2.numel(), (20_000_000 * B_INSERT_NEW + 1_000_000 * B_INSERT_DUP) / b2.numel()),
+                               workload="2*10^7 new keys + 10^6 repeats, shuffled, into a table holding 8*10^7 keys (capacity %d stays); "
+                                        "existing slots are re-laid out with the batch (32 B per old slot on top of the 8d figure)" % cap2,
+                               fused_insert_launches="%d of 4" % fused)
+    del extra_k, b2, v2
+    torch.cuda.empty_cache()
+    # ---- configs[2] / W3: linear-probe table, 2*10^7 31-mers x 5 = 10^8 pairs, insert + count of all distinct + 2*10^6 misses
+    base, k3, v3 = gpu_w3(20_000_000, dev)
+    miss3 = dmiss[:2_000_000] | (1 << 62)                   # bit 62 set: never a 62-bit k-mer
+    q3 = torch.cat([base, miss3]).contiguous()
+    ms3 = {"insert": [], "count": []}
+    for rep in range(4):
+        t = kh.hashmap_linearprobe_doubling(128, 0.35, 0.8, hash=args.hash, seed=43)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record(); ni = t.insert(k3, v3)
+        ev[1].record(); c = t.count(q3)
+        ev[2].record(); torch.cuda.synchronize()
+        assert ni == 20_000_000 and t.size() == 20_000_000
+        assert int(c[:20_000_000].sum().item()) == 20_000_000 and int(c[20_000_000:].sum().item()) == 0
+        cap3 = t.capacity()
+        t.close()
+        if rep:
+            ms3["insert"].append(ev[0].elapsed_time(ev[1])); ms3["count"].append(ev[1].elapsed_time(ev[2]))
+    out["lp_config2"] = {"workload": "configs[2] (W3): hashmap_linearprobe_doubling, 2*10^7 distinct 62-bit 31-mers x 5 = 10^8 shuffled pairs "
+                                     "(capacity %d), count of the 2*10^7 distinct keys + 2*10^6 misses; checked: size, every distinct key counted 1, "
+                                     "every miss 0" % cap3,
+                         "insert": _stat(ms3["insert"], 100_000_000, (20_000_000 * B_INSERT_NEW + 80_000_000 * B_INSERT_DUP) / 100_000_000),
+                         "count": _stat(ms3["count"], q3.numel(), (20_000_000 * B_COUNT + 2_000_000 * B_FIND_MISS) / q3.numel())}
     return out
 
 
@@ -375,6 +606,9 @@ def run_rank(args):
         assert g_ins == n_distinct and g_size == n_distinct, (g_ins, n_distinct)
     assert g_hit == args.queries * world, (g_hit, args.queries * world)
 
+    extras = None
+    if not distributed and not args.no_extras and args.workload == "w2":
+        extras = run_extras(args, dev, keys, vals, q, dk, dv, dq)
     if rank == 0:
         ops_per_step = (args.keys + args.queries) * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -452,6 +686,8 @@ def run_rank(args):
         }
         if distributed:
             out["phases_ms_per_step_rank0"] = {k: round(v / args.steps, 4) for k, v in sorted(phases.items())}
+        if extras:
+            out.update(extras)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
@@ -469,6 +705,7 @@ def parse(argv):
     ap.add_argument("--keys", type=int, default=0, help="keys per GPU (0 = 107374184 at N=1: load exactly 0.800; 10^8 per rank at N>1)")
     ap.add_argument("--queries", type=int, default=QUERIES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N == 1: skip the informational legs (five phases for both tables, host-inclusive, W1, second batch, configs[2])")
     ap.add_argument("--workload", default="w2", choices=["w2", "w1"],
                     help="w2 = configs[1] (default, the metric's workload); w1 = benchmark_hashtables shape (x5.5 multiplicity), informational")
     ap.add_argument("--hash", default="murmur3avx64", choices=["murmur3avx64", "murmur", "farm", "identity"],
