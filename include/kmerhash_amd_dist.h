@@ -90,7 +90,7 @@ kh_status khd_insert(khd_map* m, const uint64_t* keys_dev, const uint32_t* vals_
  * khd_count and khd_find only QUEUE their work: the outputs are complete in the order of the map's stream (khd_set_stream), or after
  * khd_synchronize, which also reports whether every rank's local part succeeded. */
 kh_status khd_count(khd_map* m, const uint64_t* keys_dev, uint64_t n, uint64_t* out_keys_dev, uint8_t* out01_dev);
-/* find_p (:1619): values (untouched on a miss) and found flags aligned with the permuted keys */
+/* find_p (:1619): values (0 on a miss) and found flags aligned with the permuted keys */
 kh_status khd_find(khd_map* m, const uint64_t* keys_dev, uint64_t n, uint64_t* out_keys_dev, uint32_t* out_vals_dev, uint8_t* out_found_dev);
 /* erase_p (:2169): number erased from this rank's local table */
 kh_status khd_erase(khd_map* m, const uint64_t* keys_dev, uint64_t n, uint64_t* n_erased_local);

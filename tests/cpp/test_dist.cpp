@@ -271,8 +271,9 @@ static void pipelined_queries(int P, size_t nq, bool timing) {
   std::vector<khd_map*> maps(P);
   OK(khd_create_local(maps.data(), P, 0, KH_KIND_ROBINHOOD, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, KH_HASH_MURMUR3_X86_128_LO64, KHD_DIST_SEED));
   std::vector<std::vector<uint64_t> > keys(P), q(P); std::vector<std::vector<uint32_t> > vals(P);
-  for (int r = 0; r < P; ++r) {
+  for (int r = 0; r < P; ++r)
     for (size_t i = 0; i < nq; ++i) { uint64_t d = (uint64_t(r + 1) << 40) + i; keys[r].push_back(splitmix(d)); vals[r].push_back(uint32_t(r * 100000000u + i)); }
+  for (int r = 0; r < P; ++r) {
     uint64_t s = 17 + r;
     for (size_t i = 0; i < nq; ++i) q[r].push_back(i % 4 ? keys[(r + i) % P][splitmix(s) % nq] : (splitmix(s) | 1ull << 63));     // other ranks' keys + misses
   }
@@ -309,7 +310,7 @@ static void pipelined_queries(int P, size_t nq, bool timing) {
   for (int r = 0; r < P; ++r) {
     CHECK(ok1[r] == okN[r] && f1[r] == fN[r] && c1[r] == cN[r] && c1[r] == f1[r]);        // same permuted order, same flags
     size_t hits = 0;
-    for (size_t i = 0; i < nq; ++i) if (f1[r][i]) { CHECK(v1[r][i] == vN[r][i]); ++hits; } else CHECK(vN[r][i] == 0xEEEEEEEEu);      // a miss leaves the value untouched
+    for (size_t i = 0; i < nq; ++i) if (f1[r][i]) { CHECK(v1[r][i] == vN[r][i]); ++hits; } else CHECK(vN[r][i] == 0u && v1[r][i] == 0u);      // the value of a miss is 0
     CHECK(hits > nq / 2 && hits < nq);
   }
   double a = 0, b = 0; for (int r = 0; r < P; ++r) { a = std::max(a, ms1[r]); b = std::max(b, msN[r]); }
@@ -318,7 +319,37 @@ static void pipelined_queries(int P, size_t nq, bool timing) {
 }
 
 int main(int argc, char** argv) {
-  if (argc > 1 && !std::strcmp(argv[1], "--query-timing")) { pipelined_queries(4, 10000000, true); return 0; }
+  setvbuf(stdout, nullptr, _IOLBF, 0);      // (progress survives a crash when stdout is a pipe)
+  if (argc > 1 && !std::strcmp(argv[1], "--query-timing")) {
+    pipelined_queries(4, 10000000, true);
+    // the same question over RCCL (one rank, forced self-exchange): what a piece costs in launches when nothing can overlap
+    char id[KHD_UNIQUE_ID_BYTES];
+    OK(khd_unique_id(id));
+    khd_map* m = nullptr;
+    OK(khd_create(&m, id, 1, 0, 0, KH_KIND_ROBINHOOD, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, KH_HASH_MURMUR3_X86_128_LO64, KHD_DIST_SEED));
+    OK(khd_set_option(m, KHD_OPT_FORCE_COLLECTIVES, 1));
+    const size_t n = 100000000, nq = 10000000;
+    std::vector<uint64_t> k(n); std::vector<uint32_t> v(n);
+    for (size_t i = 0; i < n; ++i) { uint64_t d = (uint64_t(1) << 40) + i; k[i] = splitmix(d); v[i] = uint32_t(i); }
+    uint64_t* dk = dev(k); uint32_t* dv = dev(v); uint64_t x = 0;
+    OK(khd_insert(m, dk, dv, n, 4, 0, &x)); CHECK(x == n);
+    uint64_t* ok = dev(std::vector<uint64_t>(nq)); uint32_t* ov = dev(std::vector<uint32_t>(nq)); uint8_t* of = dev(std::vector<uint8_t>(nq));
+    for (int pieces : {1, 2, 4, 8}) {
+      OK(khd_set_option(m, KHD_OPT_QUERY_PIECES, pieces));
+      double best = 1e30;
+      for (int rep = 0; rep < 6; ++rep) {
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        auto t0 = std::chrono::steady_clock::now();
+        OK(khd_find(m, dk, nq, ok, ov, of)); OK(khd_synchronize(m));
+        best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      }
+      char buf[512]; OK(khd_phase_ms(m, buf, sizeof(buf)));
+      std::string ph(buf); for (auto& c : ph) if (c == '\n') c = ' ';
+      std::printf("rccl one rank forced, %zu finds in a 1e8-key table, %d piece(s): %.3f ms   [device ms over 6 reps: %s]\n", nq, pieces, best, ph.c_str());
+    }
+    OK(khd_destroy(m));
+    return 0;
+  }
   {  // one RCCL rank
     char id[KHD_UNIQUE_ID_BYTES];
     OK(khd_unique_id(id));
@@ -347,7 +378,7 @@ int main(int argc, char** argv) {
     OK(khd_set_option(m, KHD_OPT_QUERY_PIECES, 3));
     kh_table* plain = nullptr;
     OK(kh_create(&plain, KH_KIND_ROBINHOOD, 8, 4, KH_HASH_MURMUR3_X86_128_LO64, 43, 128, 0.35f, 0.8f, 0));
-    const size_t n = 3000000;       // (>= 2^20 pairs per piece at 2^10 partitions: the repeatable streamed insert's histogram-free layout)
+    const size_t n = 4500000;       // (capacity 2^23 = 2^12 partitions of ~1100 pairs: the repeatable streamed insert takes its histogram-free layout)
     std::vector<uint64_t> k(n); std::vector<uint32_t> v(n);
     uint64_t s = 11; for (size_t i = 0; i < n; ++i) { k[i] = splitmix(s); v[i] = uint32_t(i); }
     for (size_t i = 0; i < 5000; ++i) k[n - 1 - i] = k[i * 7];          // duplicates the first piece's sample cannot see: the retry path over RCCL
@@ -367,7 +398,9 @@ int main(int argc, char** argv) {
     OK(khd_find(m, dq, nq, ok, ov, of)); OK(khd_count(m, dq, nq, nullptr, oc)); OK(khd_synchronize(m));
     OK(kh_find(plain, dq, nq, KH_MEM_DEVICE, pv, pf, nullptr));
     CHECK(hipDeviceSynchronize() == hipSuccess);
-    CHECK(host(ok, nq) == q && host(ov, nq) == host(pv, nq) && host(of, nq) == host(pf, nq) && host(oc, nq) == host(pf, nq));      // one rank: permuted order == input order
+    CHECK(host(ok, nq) == q && host(of, nq) == host(pf, nq) && host(oc, nq) == host(pf, nq));      // one rank: permuted order == input order
+    { auto a = host(ov, nq), b = host(pv, nq); auto f = host(pf, nq);
+      for (size_t i = 0; i < nq; ++i) CHECK(f[i] ? a[i] == b[i] : a[i] == 0u); }                   // the value of a miss is 0 in the sharded form
     OK(khd_erase(m, dq, nq, &ne)); OK(kh_erase(plain, dq, nq, KH_MEM_DEVICE, &nep));
     CHECK(ne == nep && ne > 0);
     CHECK(contents(khd_local(m)) == contents(plain));

@@ -38,7 +38,7 @@ def _worker(port, q):
         from kmerhash_amd import workloads as W
         from kmerhash_amd import dist as khd
         assert khd.FORCE_COLLECTIVES
-        n = 3_000_000
+        n = 4_500_000                                     # capacity 2^23: 2^12 partitions, the histogram-free layout of the pieces
         keys = W.distinct_u64(n, seed=5)
         vals = np.arange(n, dtype=np.uint32)
         keys[n - 4000:] = keys[100:4100]              # duplicates the first piece's sample cannot see: KhRetry inside the sharded insert
@@ -55,7 +55,7 @@ def _worker(port, q):
         a, b = st.local.sorted_items(), plain.sorted_items()
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
         # pipelined queries (3 pieces) over RCCL: permuted order of ONE rank == input order
-        q1 = np.concatenate([keys[:700_000], W.distinct_u64(300_000, seed=77)])
+        q1 = np.concatenate([keys[:900_000], W.distinct_u64(300_000, seed=77)])
         q1 = q1[W.shuffle_perm(len(q1), 3)]
         dq = torch.from_numpy(q1.view(np.int64)).cuda()
         st.query_pieces = 3

@@ -1158,7 +1158,11 @@ def test_reducer_plus_speculation_never_touches_live_counts(kname, cls, kind):
     base = W.distinct_u64(1000, seed=3)
     fresh = W.distinct_u64(n, seed=4)
     k = fresh.copy()
-    k[(n // 65536) * np.arange(30_000) + 1] = fresh[7]              # one key 30000 times, between the sample's positions
+    # one key 30000 times, at positions neither sample looks at: the one-shot insert samples every (n // 65536) = 61st key, the
+    # streamed form every (1_500_000 // 65536) = 22nd key of its first piece
+    cand = np.arange(n)
+    cand = cand[(cand % 61 != 0) & (cand % 22 != 0)]
+    k[cand[::100][:30_000]] = fresh[7]
     k[(n // 65536) * np.arange(40_000, 40_600) + 2] = base[:600]      # keys the table already holds (counts must grow by exactly 1)
     k[(n // 65536) * np.arange(41_000, 41_100) + 2] = base[:100]      # ... some of them twice
 
