@@ -63,8 +63,8 @@ enum {
   KHD_OPT_FORCE_COLLECTIVES = 1, /* != 0: a map of ONE rank runs the exchange code of the multi-rank case (count exchange, grouped
                                     all-to-all-v per piece, votes) instead of the short cut to its local table; also set by the environment
                                     variable KH_DIST_FORCE_COLLECTIVES=1 at creation.  (Runs every RCCL call of the library on a one-GPU box.) */
-  KHD_OPT_QUERY_PIECES = 2,      /* pieces a find / count batch of THIS rank is exchanged in (1..8; 0 = by size: 4 from 2^22 keys, 2 from
-                                    2^20): the keys of piece i+1 travel while piece i is looked up and its results return
+  KHD_OPT_QUERY_PIECES = 2,      /* pieces a find / count batch of THIS rank is exchanged in (1..8; 0 = by size: 4 from 2^23 keys, 2 from
+                                    2^22): the keys of piece i+1 travel while piece i is looked up and its results return
                                     (khmxx::ialltoallv_and_query_one_to_one, incremental_mxx.hpp:4403-4669).  May differ between ranks. */
   KHD_OPT_TIMEOUT_MS = 3         /* how long a rank waits for its peers inside a collective before it aborts the communicator (default
                                     300000; environment KHD_TIMEOUT_MS) */

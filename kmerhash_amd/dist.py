@@ -502,7 +502,7 @@ class ShardedTable:
         if self.query_pieces > 0:
             return min(int(self.query_pieces), MAX_QUERY_PIECES)
         n = keys.numel()
-        return 4 if n >= (1 << 22) else (2 if n >= (1 << 20) else 1)
+        return 4 if n >= (1 << 23) else (2 if n >= (1 << 22) else 1)      # (every piece costs ~0.05 ms of launches: kmerhash_amd_dist.cpp)
 
     def _query(self, keys, op):
         """keys out (grouped by owner, in pieces), the local query of a piece while the next one travels, results back with the

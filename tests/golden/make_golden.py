@@ -11,6 +11,9 @@
                     unbuildable here -- see oracle/kh_oracle.hpp); they carry the occupancy bitmap of the real
                     reference LP table for the same keys, which the RH table must reproduce slot for slot.
 
+  ops_ref_<name>.npz    single-key insert / update / single-key erase / a counting insert through the REAL reference LP table's members:
+                    kind-independent map results, which the Robin Hood table (GPU and oracle) must reproduce as well.
+
 Fixtures are data only (inputs + expected outputs); no reference source is stored.
 """
 import os
@@ -92,6 +95,49 @@ def scenario(name, n, seed, hash_id, cap0=128, mn=0.35, mx=0.8):
     np.savez_compressed(os.path.join(HERE, "rh_oracle_%s.npz" % name), **rh)
 
 
+def ops_scenario(name, n, seed, hash_id, cap0=128, mn=0.35, mx=0.8):
+    """ops_ref_<name>.npz: the single-key members and update() of the REAL reference LP table, and a counting insert composed from
+    its own find / update / insert (what Reducer = std::plus computes: old value + 1 per occurrence).  All results here are map
+    semantics independent of the table kind (first value wins, last update wins, erase counts, sums): the Robin Hood GPU table and
+    the Robin Hood oracle are held to them too; capacities are recorded for the LP kind only."""
+    keys, vals = W.w1_benchmark_hashtables(n, seed=seed)
+    if hash_id == O.HASH_IDENTITY:
+        keys = W.splitmix64(keys)
+    h = n // 2
+    fresh = W.distinct_u64(400, seed=seed + 5)
+    one_k = np.concatenate([keys[h:h + 200], fresh[:100], keys[:100]])                  # new, new, duplicates
+    one_k = one_k[W.shuffle_perm(len(one_k), seed + 6)]
+    one_v = (np.arange(len(one_k), dtype=np.uint32) + np.uint32(5_000_000))
+    upd_k = np.concatenate([keys[:300], fresh[100:250], keys[100:200], fresh[100:150]])   # existing, new, and keys given twice
+    upd_k = upd_k[W.shuffle_perm(len(upd_k), seed + 7)]
+    upd_v = (np.arange(len(upd_k), dtype=np.uint32) + np.uint32(7_000_000))
+    er_k = np.concatenate([keys[50:250], fresh[250:350], keys[50:100]])                   # hits, misses, already erased
+    er_k = er_k[W.shuffle_perm(len(er_k), seed + 8)]
+    rng = np.random.default_rng(seed)
+    cnt_k = np.concatenate([keys[rng.integers(0, n, 3000)], fresh[300:400][rng.integers(0, 100, 800)]])
+    out = dict(keys=keys[:h], vals=vals[:h], one_k=one_k, one_v=one_v, upd_k=upd_k, upd_v=upd_v, er_k=er_k, cnt_k=cnt_k,
+               params=np.array([cap0, hash_id, 43], dtype=np.uint64), lfs=np.array([mn, mx], dtype=np.float32))
+    t = O.RefLPTable(cap0, mn, mx, hash_id, 43)
+    out["n_inserted"] = np.uint64(t.insert(keys[:h], vals[:h]))
+    out["one_flags"] = np.array([1 if t.insert_one(int(k), int(v)) else 0 for k, v in zip(one_k, one_v)], dtype=np.uint8)
+    out["size_one"] = np.uint64(t.size()); out["lp_cap_one"] = np.uint64(t.capacity())
+    for k, v in zip(upd_k, upd_v):
+        t.update_one(int(k), int(v))
+    out["size_upd"] = np.uint64(t.size()); out["lp_cap_upd"] = np.uint64(t.capacity())
+    sk, sv = t.sorted_items(); out["items_upd_k"] = sk; out["items_upd_v"] = sv
+    out["er_flags"] = np.array([t.erase_one(int(k)) for k in er_k], dtype=np.uint8)
+    out["size_er"] = np.uint64(t.size()); out["lp_cap_er"] = np.uint64(t.capacity())
+    for k in cnt_k:                       # counting insert, one occurrence at a time, through the reference's own members
+        fk, fv = t.find_compact(np.array([k], dtype=np.uint64))
+        if len(fk):
+            t.update_one(int(k), (int(fv[0]) + 1) & 0xFFFFFFFF)
+        else:
+            t.insert_one(int(k), 1)
+    out["size_cnt"] = np.uint64(t.size())
+    sk, sv = t.sorted_items(); out["items_cnt_k"] = sk; out["items_cnt_v"] = sv
+    np.savez_compressed(os.path.join(HERE, "ops_ref_%s.npz" % name), **out)
+
+
 def hll_and_io():
     """hll_ref.npz: registers/estimates of the REAL reference hyperloglog64<uint64_t,Hash,12>; io_ref_pairs.bin /
     io_ref_keys.bin: files written by the REAL reference serialize_vector (io_utils.hpp:57-81)."""
@@ -125,5 +171,7 @@ if __name__ == "__main__":
     scenario("farm_5k", 5000, 13, O.HASH_FARM)
     scenario("identity_5k", 5000, 17, O.HASH_IDENTITY)
     scenario("lpdefaults_3k", 3000, 19, O.HASH_MURMUR3_X86, 128, 0.2, 0.6)
+    ops_scenario("murmur_4k", 4000, 29, O.HASH_MURMUR3_X86)
+    ops_scenario("farm_4k", 4000, 31, O.HASH_FARM)
     hll_and_io()
     print("golden fixtures written to", HERE)

@@ -29,7 +29,9 @@ def test_murmur3_kat_on_gpu():
 def replay(t, g, pfx, rh):
     assert t.insert(g["keys"], g["vals"]) == int(g[pfx + "n_inserted"])
     assert (t.size(), t.capacity()) == (int(g[pfx + "size1"]), int(g[pfx + "cap1"]))
-    if rh:
+    if rh is None:
+        pass           # results only (a Robin Hood table replaying the reference LP table's outputs)
+    elif rh:
         assert np.array_equal(t.export_info(), g[pfx + "info1"])
         assert np.array_equal(t.export_info() >= 0x80, g["ref_lp_occupied1"])
     else:
@@ -59,10 +61,49 @@ def test_gpu_lp_matches_reference_fixture(path):
     t.close()
 
 
+KIND_FREE = ("n_inserted", "size1", "count1", "findk1", "findv1", "n_erased", "size2", "count2", "n_inserted2", "size3", "items3k", "items3v", "count3")
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "rh_oracle_*.npz"))), ids=os.path.basename)
 def test_gpu_rh_matches_fixture(path):
     g = np.load(path)
     cap0, hid, seed = (int(x) for x in g["params"])
     t = kh.hashmap_robinhood_doubling(cap0, float(g["lfs"][0]), float(g["lfs"][1]), hash=HNAME[hid], seed=seed)
     replay(t, g, "rh_", rh=True)
+    t.close()
+    # the RESULTS of the Robin Hood table pinned to the REAL reference: the sibling lp_ref_<name>.npz holds the reference LP table's
+    # outputs for the same inputs, and everything but layout and post-erase capacity is kind-independent map semantics
+    ref = np.load(path.replace("rh_oracle_", "lp_ref_"))
+    for f in ("keys", "vals", "q", "er", "keys2", "vals2"):
+        assert np.array_equal(g[f], ref[f])
+    pinned = {k: ref[k] for k in ("keys", "vals", "q", "er", "keys2", "vals2")}
+    pinned.update({"lp_" + f: ref["lp_" + f] for f in KIND_FREE})
+    pinned.update({"lp_cap1": g["rh_cap1"], "lp_cap2": g["rh_cap2"], "lp_cap3": g["rh_cap3"], "lp_info1": None})
+    t = kh.hashmap_robinhood_doubling(cap0, float(g["lfs"][0]), float(g["lfs"][1]), hash=HNAME[hid], seed=seed)
+    replay(t, pinned, "lp_", rh=None)
+    t.close()
+
+
+@pytest.mark.parametrize("kname,cls", [("rh", kh.hashmap_robinhood_doubling), ("lp", kh.hashmap_linearprobe_doubling)])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ops_ref_*.npz"))), ids=os.path.basename)
+def test_gpu_single_key_update_and_counting_match_reference(path, kname, cls):
+    """insert(value_type), update(k,v), erase(key) and a counting insert against outputs of the REAL reference LP table's members
+    (tests/golden/make_golden.py ops_scenario): kind-independent results for both GPU tables, capacities for the LP one"""
+    g = np.load(path)
+    cap0, hid, seed = (int(x) for x in g["params"])
+    lp = kname == "lp"
+    t = cls(cap0, float(g["lfs"][0]), float(g["lfs"][1]), hash=HNAME[hid], seed=seed)
+    assert t.insert(g["keys"], g["vals"]) == int(g["n_inserted"])
+    flags = np.array([t.insert_one(int(k), int(v)) for k, v in zip(g["one_k"], g["one_v"])], dtype=np.uint8)
+    assert np.array_equal(flags, g["one_flags"])
+    assert t.size() == int(g["size_one"]) and (not lp or t.capacity() == int(g["lp_cap_one"]))
+    t.update(g["upd_k"], g["upd_v"])                 # kh_update = the update(k,v) calls in batch order: last value wins
+    assert t.size() == int(g["size_upd"]) and (not lp or t.capacity() == int(g["lp_cap_upd"]))
+    sk, sv = t.sorted_items()
+    assert np.array_equal(sk, g["items_upd_k"]) and np.array_equal(sv, g["items_upd_v"])
+    assert np.array_equal(np.array([t.erase_one(int(k)) for k in g["er_k"]], dtype=np.uint8), g["er_flags"])
+    assert t.size() == int(g["size_er"]) and (not lp or t.capacity() == int(g["lp_cap_er"]))
+    t.insert_reduce_plus(g["cnt_k"])                 # Reducer = std::plus, 1 per occurrence
+    sk, sv = t.sorted_items()
+    assert t.size() == int(g["size_cnt"]) and np.array_equal(sk, g["items_cnt_k"]) and np.array_equal(sv, g["items_cnt_v"])
     t.close()
