@@ -166,6 +166,11 @@ kh_status kh_erase_one(kh_table* t, uint64_t key, uint64_t* n_erased);
 kh_status kh_to_vector(kh_table* t, uint64_t* keys_host, uint32_t* vals_host, uint64_t* n_out); /* to_vector() :388, slot order */
 kh_status kh_export_info(kh_table* t, uint8_t* out_host /* capacity bytes, reference encoding of the table's kind */);
 kh_status kh_export_slots(kh_table* t, uint64_t* keys_host, uint32_t* vals_host /* capacity entries; empty slots unspecified */);
+/* the table as it lies: capacity entries of 16 bytes {u64 key, u32 value, u32 info}; the low byte of `info` is the reference's
+ * info byte of the table's kind (hashmap_robinhood.hpp:137-163 / hashmap_linearprobe.hpp:109-139), key and value of an empty slot are
+ * unspecified.  What the reference exposes as `container` + `info_container` to its iterators (hashmap_robinhood.hpp:295-309); the
+ * C++ shim probes such a snapshot on the host for loops of single-key const calls (find(key) / count(key), :1102,:1165). */
+kh_status kh_export_raw_slots(kh_table* t, void* out_host /* capacity x 16 B */);
 kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]); /* RH only: #slots per probe distance (REPROBE_STAT) */
 
 /* ---- batched hashing: Hash::operator()(Key const*, count, out)  murmurhash3_64_avx.hpp:1584-1597, hash_new.hpp:1035-1056 */

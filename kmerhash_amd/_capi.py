@@ -20,7 +20,7 @@ SYMBOLS = [
     "kh_create", "kh_destroy", "kh_set_stream", "kh_set_key_transform", "kh_get_key_transform", "kh_hash_batch_transformed", "kh_shard_permute_transformed", "kh_last_error", "kh_size", "kh_capacity", "kh_get_load_thresholds",
     "kh_set_min_load_factor", "kh_set_max_load_factor", "kh_get_load_factors", "kh_clear", "kh_reserve", "kh_rehash",
     "kh_insert", "kh_insert_pairs", "kh_insert_one", "kh_update", "kh_insert_reduce_plus", "kh_insert_begin", "kh_insert_begin_ex", "kh_insert_feed", "kh_insert_end", "kh_insert_abort", "kh_count", "kh_find", "kh_find_compact", "kh_find_compact_pairs",
-    "kh_erase", "kh_erase_one", "kh_to_vector", "kh_export_info", "kh_export_slots", "kh_displacement_histogram",
+    "kh_erase", "kh_erase_one", "kh_to_vector", "kh_export_info", "kh_export_slots", "kh_export_raw_slots", "kh_displacement_histogram",
     "kh_hash_batch", "kh_shard_permute", "kh_shard_plan_create", "kh_shard_plan_permute", "kh_shard_plan_permute_global", "kh_shard_plan_offsets", "kh_shard_plan_destroy", "kh_profile_enable", "kh_profile_reset", "kh_profile_query", "kh_profile_dump",
     "kh_kmers_from_sequence", "kh_kmers_from_fastq", "kh_hll_create", "kh_hll_destroy", "kh_hll_set_stream", "kh_hll_update", "kh_hll_update_via_hashval",
     "kh_hll_merge", "kh_hll_clear", "kh_hll_registers", "kh_hll_estimate", "kh_release_cached_memory", "kh_version",
@@ -97,6 +97,7 @@ def lib():
     L.kh_to_vector.argtypes = [vp, vp, vp, pu64]
     L.kh_export_info.argtypes = [vp, vp]
     L.kh_export_slots.argtypes = [vp, vp, vp]
+    L.kh_export_raw_slots.argtypes = [vp, vp]
     L.kh_displacement_histogram.argtypes = [vp, vp]
     L.kh_hash_batch.argtypes = [i32, u64, vp, u64, i32, vp, i32, vp]
     L.kh_shard_permute.argtypes = [i32, u64, u32, vp, vp, u64, vp, vp, vp, i32, vp]

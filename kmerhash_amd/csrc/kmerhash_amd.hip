@@ -1755,6 +1755,14 @@ kh_status kh_export_slots(kh_table* t, uint64_t* keys_host, uint32_t* vals_host)
   HIPCHK(hipStreamSynchronize(t->stream));
   return KH_OK;
 }
+kh_status kh_export_raw_slots(kh_table* t, void* out_host) {
+  if (!t || !out_host) return KH_ERR_INVALID;
+  if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMemcpyAsync(out_host, t->cur.s, t->cur.cap * sizeof(KhSlot), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return KH_OK;
+}
 kh_status kh_displacement_histogram(kh_table* t, uint64_t out[128]) {
   if (!t || !out) return KH_ERR_INVALID;
   for (int i = 0; i < 128; ++i) out[i] = 0;

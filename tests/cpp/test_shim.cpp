@@ -2,6 +2,7 @@
 // :97-334, test_hashmap_linearprobe_doubling.cpp:84-195) written against the shim: differential against
 // std::unordered_map::emplace (first value wins), through the reference's member names.  The map type is passed
 // as a 5-parameter template-template exactly as BenchmarkHashTables.cpp:1037-1048 does.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -169,6 +170,46 @@ void bimolecule(const char* name, size_t n) {
   std::printf("%s ok (n=%zu, distinct under lex_less=%zu)\n", name, n, gold.size() + ne);
 }
 
+// the reference benchmark's find phase as it is written: single-key const calls in a loop (BenchmarkHashTables.cpp:1134-1138).
+// After 64 such calls without a mutation the shim probes a host copy of the slot array: 10^6 calls must take well under a second
+// and agree with the batch form; a mutation drops the copy
+template <template <typename, typename, typename, typename, typename> class MAP>
+void single_key_loop(const char* name) {
+  using Map = MAP<uint64_t, uint32_t, fsc::hash::murmur3avx64<uint64_t>, ::equal_to<uint64_t>, ::std::allocator<::std::pair<uint64_t, uint32_t> > >;
+  const size_t n = 2000000, nq = 1000000;
+  std::vector<std::pair<uint64_t, uint32_t> > input(n);
+  uint64_t s = 99;
+  auto next = [&s]() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+  for (size_t i = 0; i < n; ++i) input[i] = std::make_pair(next() >> 2, uint32_t(i));
+  Map map;
+  map.set_min_load_factor(0.35f); map.set_max_load_factor(0.8f);
+  map.insert(input);
+  std::vector<uint64_t> q(nq);
+  for (size_t i = 0; i < nq; ++i) q[i] = i % 5 ? input[(i * 7919) % n].first : (next() | (uint64_t(1) << 63));      // 80 % hits
+  auto batch = map.find(q.begin(), q.end());
+  auto bcount = map.count(q.begin(), q.end());
+  const auto t0 = std::chrono::steady_clock::now();
+  size_t hits = 0, bi = 0;
+  for (size_t i = 0; i < nq; ++i) {
+    auto it = map.find(q[i]);
+    if (it != map.end()) { CHECK(bi < batch.size() && it->first == batch[bi].first && it->second == batch[bi].second); ++bi; ++hits; }
+  }
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  CHECK(hits == batch.size() && hits == nq - nq / 5);
+  size_t c1 = 0;
+  for (size_t i = 0; i < nq; ++i) { const size_t c = map.count(q[i]); CHECK(c == bcount[i]); c1 += c; }
+  CHECK(c1 == hits);
+  CHECK(sec < 1.0);
+  // a mutation drops the host copy: the next single-key calls see it (and go to the GPU again)
+  const uint64_t fresh = (uint64_t(1) << 63) | 12345u;
+  CHECK(map.find(fresh) == map.end());
+  map.insert(fresh, 77u);
+  CHECK(map.find(fresh) != map.end() && map.find(fresh)->second == 77u && map.count(fresh) == 1);
+  CHECK(map.erase(q[1]) == 1 && map.count(q[1]) == 0 && map.find(q[1]) == map.end());
+  for (size_t i = 0; i < 200; ++i) CHECK(map.count(q[1]) == 0 && map.count(fresh) == 1);      // (through a fresh host copy from the 65th call on)
+  std::printf("%s: %zu single-key find calls in %.3f s (%.0f ns each), equal to the batch form\n", name, nq, sec, sec / nq * 1e9);
+}
+
 int main() {
   differential<fsc::hashmap_robinhood_doubling, uint64_t, fsc::hash::murmur3avx64<uint64_t> >("rh/u64/murmur3avx64", 100000, true);
   differential<fsc::hashmap_robinhood_doubling, uint64_t, std::hash<uint64_t> >("rh/u64/std::hash", 20000, true);
@@ -189,6 +230,11 @@ int main() {
   bimolecule<fsc::hashmap_robinhood_doubling, 31, fsc::hash::farm>("rh/dna_kmer<31>/TransformedHash<farm, lex_less>", 60000);
   bimolecule<fsc::hashmap_robinhood_doubling, 21, fsc::hash::murmur3avx64>("rh/dna_kmer<21>/TransformedHash<murmur3avx64, lex_less>", 20000);
   bimolecule<fsc::hashmap_linearprobe_doubling, 31, fsc::hash::murmur>("lp/dna_kmer<31>/TransformedHash<murmur, lex_less>", 20000);
+  // k = 1 and k = 2: most bit patterns are a strand of the same k-mer as their neighbour (the constructor's Equal probe computes what it expects)
+  bimolecule<fsc::hashmap_robinhood_doubling, 1, fsc::hash::murmur3avx64>("rh/dna_kmer<1>/TransformedHash<murmur3avx64, lex_less>", 600);
+  bimolecule<fsc::hashmap_linearprobe_doubling, 2, fsc::hash::farm>("lp/dna_kmer<2>/TransformedHash<farm, lex_less>", 600);
+  single_key_loop<fsc::hashmap_robinhood_doubling>("rh single-key loop");
+  single_key_loop<fsc::hashmap_linearprobe_doubling>("lp single-key loop");
   {  // TransformedHash with the identity pre-transform is the plain functor; std::equal_to does not fit a lex_less hash
     using TH = fsc::hash::TransformedHash<uint64_t, fsc::hash::farm>;
     fsc::hashmap_robinhood_doubling<uint64_t, uint32_t, TH> m;
