@@ -33,7 +33,9 @@ def parse(argv):
     ap.add_argument("--reads", type=int, default=2_000_000, help="reads per rank")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--genome", type=int, default=20_000_000)
-    ap.add_argument("--batches", type=int, default=4, help="file batches per rank (the reference reads the input in memory-sized pieces)")
+    ap.add_argument("--batches", type=int, default=4, help="file batches per rank; 0 = sized from the free HBM the way the reference sizes its file batches "
+                                                          "from free memory (BenchmarkKmerCounter.cpp:1508-1590: k-mer estimate x working bytes + 2 x text + table growth <= usable)")
+    ap.add_argument("--host-gen", action="store_true", help="generate the reads with numpy on the host (default: on the GPU with torch; neither is timed)")
     ap.add_argument("-k", type=int, default=31)
     ap.add_argument("--hash", default="farm", choices=["farm", "murmur3avx64", "murmur"])
     ap.add_argument("--chunks", type=int, default=0, help="pieces of the pipelined exchange per batch (0 = 4 when N > 1)")
@@ -88,13 +90,43 @@ def run_rank(args):
         dist.init_process_group("nccl", device_id=dev)
     chunks = args.chunks if args.chunks > 0 else (4 if world > 1 else 1)
 
-    # ---- input: this rank's reads of the common genome (host generation is not timed)
+    # ---- input: this rank's reads of the common genome (generation is not timed)
     t0 = time.perf_counter()
-    seq, genome, starts, rev = KM.synthetic_reads(args.reads, args.read_len, args.genome, genome_seed=7, read_seed=100 + rank)   # one genome, own reads
-    fq = KM.fastq_from_sequence_lines(seq, args.reads, args.read_len)
+    if args.host_gen:
+        seq, genome, starts, rev = KM.synthetic_reads(args.reads, args.read_len, args.genome, genome_seed=7, read_seed=100 + rank)   # one genome, own reads
+        fq = KM.fastq_from_sequence_lines(seq, args.reads, args.read_len)
+        dfq = torch.from_numpy(fq).to(dev)
+        del seq, fq
+        positions_of = lambda r: torch.from_numpy((starts if r == rank else KM.read_positions(args.reads, args.read_len, args.genome, 100 + r)[0]).astype(np.int64)).to(dev)
+    else:
+        dfq, dgenome, dstarts = KM.synthetic_fastq_device(args.reads, args.read_len, args.genome, 7, 100 + rank, local)
+        genome = None
+
+        def positions_of(r):
+            if r == rank:
+                return dstarts
+            g = torch.Generator(device=dev); g.manual_seed(100 + r)
+            return torch.randint(0, args.genome - args.read_len, (args.reads,), dtype=torch.int64, device=dev, generator=g)
+    torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
-    dfq = torch.from_numpy(fq).to(dev)
-    rec = len(fq) // args.reads
+    n_text = int(dfq.numel())
+    rec = n_text // args.reads
+    if args.batches <= 0:
+        # the reference adds input files to an iteration while kmer_est x 5 x sizeof(tuple) + 2 x file_size + the table's growth stays
+        # under the usable memory (BenchmarkKmerCounter.cpp:1508-1590).  Here, per byte of FASTQ text of a batch: 8 B of k-mer output
+        # room + 1 B of masked text (kh_kmers_from_fastq), and per k-mer (0.38 per text byte at 150-bp reads) ~70 B of counting-insert
+        # workspace (partition records, lists, exchange buffers); the table (16 B x capacity, twice while it is re-laid out) on top
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        kmers_per_byte = max(args.read_len - args.k + 1, 1) / float(rec)
+        per_byte = 9.0 + kmers_per_byte * 70.0
+        table_b = 2 * 16 * (1 << max(7, int(np.ceil(np.log2(max(args.genome, 128) / 0.8)))))
+        usable = max(0.6 * free_b - table_b, 0.05 * free_b)
+        batch_bytes = min(usable / per_byte, 2.0e9 / kmers_per_byte)           # (a batch stays under 2^31 k-mers: 32-bit record indices)
+        nb = max(1, int(np.ceil(n_text / batch_bytes)))
+        args.batches = nb
+        batch_note = {"free_hbm": int(free_b), "usable": int(usable), "bytes_per_text_byte": round(per_byte, 1), "batch_text_bytes": int(n_text / nb)}
+    else:
+        batch_note = None
     cuts = [rec * (args.reads * i // args.batches) for i in range(args.batches + 1)]
 
     be = khd.GpuBackend(local, "rh", 128, 0.35, 0.8, args.hash, 43)
@@ -119,24 +151,31 @@ def run_rank(args):
     total_local = kc.total_kmers
     size_after = kc.size()
     res = {"kmers_local": total_local, "capacity_per_batch_rank0": caps, "distinct_global": size_after,
-           "insert_s": t_ins, "phases_ms_rank0": {k: round(v, 3) for k, v in st.timings().items()}}
+           "insert_s": t_ins, "phases_ms_rank0": {k: round(v, 3) for k, v in st.timings().items()}, "batch_sizing": batch_note}
 
     ok = True
     if args.verify:
         # counts predicted from the read positions of ALL ranks (cov[p] = reads covering the k-mer at genome position p)
-        cov = np.zeros(args.genome, dtype=np.int64)
+        d = torch.zeros(args.genome + 1, dtype=torch.int64, device=dev)
+        one = torch.ones(args.reads, dtype=torch.int64, device=dev)
         for r in range(world):
-            s_r = starts if r == rank else KM.read_positions(args.reads, args.read_len, args.genome, 100 + r)[0]
-            cov += KM.expected_kmer_coverage(args.genome, s_r, args.read_len, args.k)
-        exp_total = int(cov.sum())
-        exp_distinct = int((cov > 0).sum())                        # exact when the genome's k-mers are pairwise distinct (k = 31: they are)
+            s_r = positions_of(r)
+            d.index_add_(0, s_r, one)
+            d.index_add_(0, s_r + (args.read_len - args.k + 1), -one)
+        dcov = torch.cumsum(d, 0)[:args.genome]
+        exp_total = int(dcov.sum().item())
+        exp_distinct = int((dcov > 0).sum().item())                # exact when the genome's k-mers are pairwise distinct (k = 31: they are)
         rng = np.random.default_rng(99 + rank)
         pos = rng.integers(0, args.genome - args.k, 100_000)
+        cov_at = dcov[torch.from_numpy(pos).to(dev)].cpu().numpy()
+        del d, dcov, one
+        if genome is None:
+            genome = dgenome.cpu().numpy()
         qk = KM.canonical_kmers_at(genome, pos, args.k)
         pk, vals, found = st.find(torch.from_numpy(qk.view(np.int64)).to(dev))
         got = dict(zip(pk.cpu().numpy().view(np.uint64).tolist(), ((vals.cpu().numpy().view(np.uint32).astype(np.int64)) * found.cpu().numpy()).tolist()))
         exp = {}
-        for kk, c in zip(qk.tolist(), cov[pos].tolist()):
+        for kk, c in zip(qk.tolist(), cov_at.tolist()):
             exp[kk] = c                                            # (a k-mer sampled twice has the same position-independent count)
         bad = sum(1 for kk, c in exp.items() if got.get(kk, -1) != (c & 0xFFFFFFFF))
         tot = torch.tensor([total_local], dtype=torch.int64, device=dev)
@@ -157,7 +196,8 @@ def run_rank(args):
         t_cyc = time.perf_counter() - t0
         nq = int(qs.numel())
         ok = ok and cyc["count_hits"] == nq and cyc["find_hits"] == nq and cyc["count_hits_after"] == 0
-        res["cycle"] = dict(cyc, queries_local=nq, seconds=t_cyc, size_after=kc.size(), ok=bool(cyc["count_hits"] == nq and cyc["count_hits_after"] == 0))
+        res["cycle"] = dict(cyc, queries_local=nq, seconds=t_cyc, ops_per_s=4 * nq * world / t_cyc, size_after=kc.size(),
+                            ok=bool(cyc["count_hits"] == nq and cyc["count_hits_after"] == 0))
     if args.out:
         k_, v_ = be.table.to_vector()
         recs = np.zeros(len(k_), dtype=np.dtype([("kmer", "<u8"), ("count", "<u2")]))
@@ -165,7 +205,8 @@ def run_rank(args):
         recs.tofile(args.out + (".%d" % rank if world > 1 else ""))
     if rank == 0:
         res.update({"n_gpus": world, "reads_per_rank": args.reads, "batches": args.batches, "k": args.k, "hash": args.hash,
-                    "exchange_pieces": chunks, "fastq_bytes_per_rank": int(len(fq)), "host_generation_s": round(t_gen, 2),
+                    "exchange_pieces": chunks, "fastq_bytes_per_rank": n_text, "bases_per_rank": args.reads * args.read_len, "genome": args.genome,
+                    "generation_s": round(t_gen, 2),
                     "kmers_per_s": total_local * world / t_ins, "ok": bool(ok)})
         print(json.dumps(res), flush=True)
     be.table.close()

@@ -242,6 +242,9 @@ kh_status kh_hll_merge(kh_hll* h, const kh_hll* other);   /* :463 */
 kh_status kh_hll_clear(kh_hll* h);                        /* :467 */
 kh_status kh_hll_registers(kh_hll* h, uint8_t* out_host /* 2^precision bytes */);
 kh_status kh_hll_estimate(kh_hll* h, double* out);       /* :459 */
+/* internal_estimate (:201-236) on 2^precision host registers: what estimate_global (:482-484) applies to the registers merged over all
+ * ranks (merge_distributed :477-479 = an all-reduce(max) of the registers, done by the caller's communication layer).  Host only. */
+kh_status kh_hll_estimate_registers(const uint8_t* registers_host, uint32_t precision, double* out);
 
 /* ---- measurement hooks: per-kernel HIP-event timing on the table's stream (bench.py roofline) */
 kh_status kh_profile_enable(kh_table* t, int on);

@@ -23,7 +23,7 @@ SYMBOLS = [
     "kh_erase", "kh_erase_one", "kh_to_vector", "kh_export_info", "kh_export_slots", "kh_export_raw_slots", "kh_displacement_histogram",
     "kh_hash_batch", "kh_shard_permute", "kh_shard_plan_create", "kh_shard_plan_permute", "kh_shard_plan_permute_global", "kh_shard_plan_offsets", "kh_shard_plan_destroy", "kh_profile_enable", "kh_profile_reset", "kh_profile_query", "kh_profile_dump",
     "kh_kmers_from_sequence", "kh_kmers_from_fastq", "kh_hll_create", "kh_hll_destroy", "kh_hll_set_stream", "kh_hll_update", "kh_hll_update_via_hashval",
-    "kh_hll_merge", "kh_hll_clear", "kh_hll_registers", "kh_hll_estimate", "kh_release_cached_memory", "kh_version",
+    "kh_hll_merge", "kh_hll_clear", "kh_hll_registers", "kh_hll_estimate", "kh_hll_estimate_registers", "kh_release_cached_memory", "kh_version",
 ]
 
 _lib = None
@@ -113,6 +113,7 @@ def lib():
     L.kh_hll_clear.argtypes = [vp]
     L.kh_hll_registers.argtypes = [vp, vp]
     L.kh_hll_estimate.argtypes = [vp, C.POINTER(C.c_double)]
+    L.kh_hll_estimate_registers.argtypes = [vp, u32, C.POINTER(C.c_double)]
     L.kh_profile_enable.argtypes = [vp, i32]
     L.kh_profile_reset.argtypes = [vp]
     L.kh_profile_query.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), pu64]

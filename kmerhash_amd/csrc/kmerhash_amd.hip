@@ -2127,6 +2127,12 @@ kh_status kh_hll_estimate(kh_hll* h, double* out) {
   std::vector<uint8_t> regs(m);
   kh_status st = kh_hll_registers(h, regs.data());
   if (st != KH_OK) return st;
+  return kh_hll_estimate_registers(regs.data(), h->precision, out);
+}
+kh_status kh_hll_estimate_registers(const uint8_t* regs, uint32_t precision, double* out) {
+  if (!regs || !out || precision < 4 || precision > 18) return KH_ERR_INVALID;
+  const uint32_t m = 1u << precision;
+  struct { uint32_t precision; } hh = {precision}; auto* h = &hh;
   double amm;
   switch (h->precision) {
     case 4: amm = 0.673; break;

@@ -7,6 +7,41 @@ from . import _capi as K
 from .table import _Buf, _hash_id, torch
 
 
+def estimate_from_registers(registers, precision=12):
+    """internal_estimate (hyperloglog64.hpp:201-236) on host registers (uint8[2^precision]); needs no GPU"""
+    regs = np.ascontiguousarray(registers, dtype=np.uint8)
+    if regs.size != (1 << precision):
+        raise ValueError("expected %d registers" % (1 << precision))
+    d = C.c_double()
+    st = K.lib().kh_hll_estimate_registers(regs.ctypes.data, precision, C.byref(d))
+    if st != K.KH_OK:
+        raise K.KhError(st, "kh_hll_estimate_registers")
+    return d.value
+
+
+def estimate_global(hll, group=None):
+    """estimate_global (hyperloglog64.hpp:482-484): the estimate over the registers of ALL ranks, merged with an all-reduce(max)
+    (merge_distributed :477-479; RCCL when the process group's backend is nccl).  `hll`: anything with registers() -> uint8 array and
+    .precision.  Collective."""
+    import torch.distributed as dist
+    regs = np.ascontiguousarray(hll.registers(), dtype=np.uint8)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.from_numpy(regs.copy())
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        regs = t.cpu().numpy()
+    return estimate_from_registers(regs, hll.precision)
+
+
+def estimate_average_per_rank(hll, group=None):
+    """estimate_average_per_rank (hyperloglog64.hpp:487-489): the global estimate divided by the number of ranks (hashed keys spread
+    evenly): what a rank's local table must hold"""
+    import torch.distributed as dist
+    p = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    return estimate_global(hll, group) / float(p)
+
+
 class hyperloglog64:
     def __init__(self, precision=12, ignore_msb=0, hash="murmur3avx64", seed=43, device=0):
         self._L = K.lib()

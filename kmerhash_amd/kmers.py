@@ -189,12 +189,15 @@ class ShardedKmerCounter:
         """one file batch of this rank: raw FASTQ text (whole records) -> k-mers -> sharded counting insert.  Collective: every
         rank calls it once per batch (an empty batch where a rank has run out of reads)."""
         km = self.kmer_fn(text)
-        if self.reserve_from_estimate and self.hll is not None and len(km):
+        if self.reserve_from_estimate and self.hll is not None:
             # the reference sizes its counting table from a HyperLogLog estimate of the distinct k-mers seen so far (+ the
-            # estimator's standard error 1.04 / sqrt(m)) before it inserts; the estimate is per rank, of what the rank HOLDS,
-            # so it is taken over the received keys' owner-side image: every rank sees ~1/p of the global distinct set
-            self.hll.update(km)
-            est = self.hll.estimate() / max(self.st.p, 1)
+            # estimator's standard error 1.04 / sqrt(m)) before it inserts: every rank updates its registers with ITS k-mers, the
+            # registers are merged over all ranks (all-reduce(max): hyperloglog64.hpp:477-484 merge_distributed / estimate_global) and
+            # every rank reserves its share of the global estimate (estimate_average_per_rank :487-489).  Collective: all ranks, every batch.
+            from .hll import estimate_average_per_rank
+            if len(km):
+                self.hll.update(km)
+            est = estimate_average_per_rank(self.hll, self.st.group)
             self.st.local.reserve(int(est * (1.0 + self.hll.est_error_rate)))
         self.st.insert_counts(km, chunks=self.chunks)
         self.total_kmers += len(km)
@@ -203,13 +206,24 @@ class ShardedKmerCounter:
     def cycle(self, queries):
         """count -> find -> erase -> count over `queries` (this rank's sample; collective).  Returns per-rank numbers:
         hits of the first count, sum of the counts find returned, keys erased on this rank's local table, hits afterwards."""
-        _, c1 = self.st.count(queries)
-        _, vals, found = self.st.find(queries)
-        erased = self.st.erase(queries)
-        _, c2 = self.st.count(queries)
+        import time
+        cuda = getattr(queries, "is_cuda", False)
+
+        def lap(t0):
+            if cuda:
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3
+
+        ms = {}
+        t0 = time.perf_counter(); _, c1 = self.st.count(queries); ms["count"] = lap(t0)
+        t0 = time.perf_counter(); _, vals, found = self.st.find(queries); ms["find"] = lap(t0)
+        t0 = time.perf_counter(); erased = self.st.erase(queries); ms["erase"] = lap(t0)
+        t0 = time.perf_counter(); _, c2 = self.st.count(queries); ms["count2"] = lap(t0)
+        if hasattr(self.st, "synchronize"):
+            self.st.synchronize()
         occ = (vals.to(torch.int64) & 0xFFFFFFFF) * found.to(torch.int64)
         return {"count_hits": int(c1.sum()), "find_hits": int(found.sum()), "find_occurrences": int(occ.sum()),
-                "erased_local": int(erased), "count_hits_after": int(c2.sum())}
+                "erased_local": int(erased), "count_hits_after": int(c2.sum()), "phase_ms": {k: round(v, 3) for k, v in ms.items()}}
 
     def size(self):
         return self.st.size()
@@ -280,3 +294,41 @@ def canonical_kmers_at(genome, positions, k):
         fw = (fw << np.uint64(2)) | c
         rc |= (np.uint64(3) - c) << np.uint64(2 * j)
     return np.minimum(fw, rc)
+
+
+def synthetic_fastq_device(n_reads, read_len, genome_len, genome_seed, read_seed, device, chunk=1_000_000):
+    """the reads of synthetic_reads / fastq_from_sequence_lines generated ON THE GPU (torch): for inputs of BenchmarkKmerCounter's
+    size (configs[4]: 6.25 Gbp per rank = 4.2e7 reads, 13 GB of FASTQ text) host generation would take minutes.  Returns
+    (fastq text: uint8 CUDA tensor of n_reads fixed-width records, genome codes: uint8 CUDA tensor, read starts: int64 CUDA tensor).
+    The generator is torch's (not numpy's): the reads differ from synthetic_reads', the prediction of every count from the read
+    positions works the same way."""
+    dev = torch.device("cuda", device)
+    g = torch.Generator(device=dev); g.manual_seed(genome_seed)
+    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=g)
+    g.manual_seed(read_seed)
+    starts = torch.randint(0, genome_len - read_len, (n_reads,), dtype=torch.int64, device=dev, generator=g)
+    rev = torch.randint(0, 2, (n_reads,), dtype=torch.uint8, device=dev, generator=g).bool()
+    w = 1 + 11 + 1 + (read_len + 1) + 2 + (read_len + 1)
+    out = torch.empty((n_reads, w), dtype=torch.uint8, device=dev)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    ar = torch.arange(read_len, dtype=torch.int64, device=dev)[None, :]
+    o = 13 + read_len + 1
+    for c0 in range(0, n_reads, chunk):
+        c1 = min(n_reads, c0 + chunk)
+        blk = out[c0:c1]
+        blk[:, 0] = ord("@")
+        ids = torch.arange(c0, c1, dtype=torch.int64, device=dev)
+        for d in range(11):
+            blk[:, 11 - d] = (ord("0") + (ids % 10)).to(torch.uint8)
+            ids = ids // 10
+        blk[:, 12] = 10
+        r = genome[starts[c0:c1, None] + ar]
+        rr = rev[c0:c1]
+        r[rr] = (3 - r[rr]).flip(1)
+        blk[:, 13:13 + read_len] = lut[r.long()]
+        blk[:, 13 + read_len] = 10
+        blk[:, o] = ord("+"); blk[:, o + 1] = 10
+        blk[:, o + 2:o + 2 + read_len] = ord("I")
+        blk[:, o + 2 + read_len] = 10
+        del r
+    return out.reshape(-1), genome, starts

@@ -48,6 +48,26 @@ def _worker(rank, world, port, q):
         be.table.t.close()
         be.table.t = O.OracleTable(O.KIND_RH, 128, 0.35, 0.8, O.HASH_FARM, 43)               # farmhash storage hash, capacity 128: doubles under load
         kc = KM.ShardedKmerCounter(ShardedTable(be), k, True, kmer_fn=kmer_fn, chunks=2)
+
+        # --hll-reserve at p > 1: every rank's registers merged by an all-reduce(max), the GLOBAL estimate / p reserved on every rank
+        # (hyperloglog64.hpp:477-489).  The oracle HLL stands in for the GPU one; the estimate formula is the library's (host code).
+        class Hll:
+            precision = 12
+            est_error_rate = 1.04 / 64.0
+
+            def __init__(s):
+                s.o = O.OracleHLL(12, 0, O.HASH_FARM, 43)
+
+            def update(s, km):
+                s.o.update(km.numpy().view(np.uint64))
+
+            def registers(s):
+                return s.o.registers()
+        from kmerhash_amd import hll as HL
+        be2 = OracleBackend(O, O.KIND_RH)
+        be2.table.reserve = lambda n: be2.table.t.reserve(int(n))
+        hl = Hll()
+        kc2 = KM.ShardedKmerCounter(ShardedTable(be2), k, True, kmer_fn=kmer_fn, chunks=1, reserve_from_estimate=True, hll=hl)
         lines = mine.split(b"\n")
         nb = 3                                                                             # three file batches, cut at record boundaries
         total = 0
@@ -55,6 +75,18 @@ def _worker(rank, world, port, q):
             part = lines[4 * (n_reads * b // nb): 4 * (n_reads * (b + 1) // nb)]
             total += kc.add_fastq(b"\n".join(part) + b"\n")
         assert be.table.t.capacity() > 128
+        kc2.add_fastq(mine)
+        # the merged registers are those of ONE estimator fed every rank's k-mers; all ranks computed the same global estimate
+        allmine = [None] * world
+        dist.all_gather_object(allmine, np_kmers_fastq(mine, k, True))
+        one = O.OracleHLL(12, 0, O.HASH_FARM, 43)
+        for a in allmine:
+            one.update(a)
+        g_est = HL.estimate_global(hl)
+        assert g_est == one.estimate() == HL.estimate_from_registers(one.registers(), 12)
+        n_dist = len(np.unique(np.concatenate(allmine)))
+        assert abs(g_est - n_dist) < 0.08 * n_dist
+        assert be2.table.t.capacity() >= int(g_est / world / 0.8)            # reserved its share before inserting
         # model: counts of all k-mers of the whole file, each on its owner rank
         allk = np_kmers_fastq(fq, k, True)
         tot = torch.tensor([total]); dist.all_reduce(tot)
