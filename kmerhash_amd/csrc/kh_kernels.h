@@ -1054,7 +1054,7 @@ __device__ __forceinline__ uint32_t kh_wave_max(uint32_t v) {
   return v;
 }
 
-enum { KH_DEDUP_FIRST = 0, KH_DEDUP_LAST = 1, KH_DEDUP_PLUS = 2 };
+enum { KH_DEDUP_FIRST = 0, KH_DEDUP_LAST = 1, KH_DEDUP_PLUS = 2, KH_DEDUP_ERASE = 3 };     // (ERASE: k_build_fused<.., 3>, no fold)
 #define KH_DD_M 2048u            // records staged per de-dup round
 
 // Folds the duplicates among the ns records staged in LDS (lk = keys, liv = idx<<32|val) into one representative per
@@ -1875,7 +1875,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   if (tid == 0) {
     s_chunk = blockIdx.x;
     s_max = 0;
-    s_abort = SRC != 1 ? (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    s_abort = (SRC == 0 || SRC == 2) ? (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   }
   __syncthreads();
   // the source table of a streamed insert lives in simg[] until the records are staged: every byte of LDS counts here
@@ -1986,6 +1986,69 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     __syncthreads();
     rep_mask = kh_dd_fold(lk, liv, set, m, P.mode, P.seed.xk);
     __syncthreads();
+  } else if (SRC == 3) {
+    // ---- batch erase without random access into HBM: the chunk's elements (home from the info byte: no hash) are staged next to the
+    // batch's erase keys of this chunk (8-byte records, partitioned by chunk like an insert batch); an element whose key is among
+    // them is dropped -- what erase_no_resize's backward shift leaves (hashmap_robinhood.hpp:1294-1356)
+    const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
+    const KhSrcView V = kh_src_setup8(P.src, q);
+    for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+    // the erase keys are requested BEFORE the table's slots (clamped indices, no branch per key: all loads of a lane in flight
+    // together), so that the chunk pays one HBM round trip for both, not two in a row
+    uint64_t kk[KH_DD_M / KH_CHUNK_THREADS];
+    {
+      const uint32_t last = V.m ? V.m - 1u : 0u;
+      const uint64_t* src8 = V.m ? V.one8 : reinterpret_cast<const uint64_t*>(P.R.Old.s);      // (an empty partition: any valid address)
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; kk[it] = src8[i < last ? i : last]; }
+    }
+    const uint32_t n_old = kh_stage_from_table<KIND, HASH, false>(P.R, c, Sc, lk, liv, &s_x, &s_max);     // (ends with a barrier)
+    m = n_old + V.m;
+    if (n_old >= KH_DD_M || m >= KH_DD_M) {      // denser than the staging area: the caller marks and re-lays out instead
+      if (tid == 0) {
+        atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+        __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      const uint32_t i = it * KH_CHUNK_THREADS + tid;
+      if (i < V.m) lk[n_old + i] = kk[it];
+    }
+    for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
+    __syncthreads();
+    // only the ERASE KEYS go into the set (a few per cent of the chunk's records: one CAS each; a key given twice meets itself);
+    // the table's elements then look themselves up read-only -- nearly every first probe meets an empty entry
+    for (uint32_t i = tid; i < V.m; i += KH_CHUNK_THREADS) {
+      const unsigned long long key = lk[n_old + i];
+      uint32_t slot = (uint32_t)kh_fmix64(kh_xf(key, P.seed.xk) + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
+      for (;;) {
+        const uint32_t cur = atomicCAS(&set[slot], 0u, n_old + i + 1u);
+        if (cur == 0 || kh_keq(lk[cur - 1u], key, P.seed.xk)) break;
+        slot = (slot + 1) & (KH_HS - 1);
+      }
+    }
+    __syncthreads();
+    uint32_t keep = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      const uint32_t x = it * KH_CHUNK_THREADS + tid;
+      if (x < n_old) {
+        const unsigned long long key = lk[x];
+        uint32_t slot = (uint32_t)kh_fmix64(kh_xf(key, P.seed.xk) + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
+        bool hit = false;
+        for (;;) {
+          const uint32_t cur = set[slot];
+          if (cur == 0) break;
+          if (kh_keq(lk[cur - 1u], key, P.seed.xk)) { hit = true; break; }
+          slot = (slot + 1) & (KH_HS - 1);
+        }
+        if (!hit) keep |= 1u << it;
+      }
+    }
+    __syncthreads();
+    rep_mask = keep;
   } else {
     m = kh_stage_from_table<KIND, HASH, false>(P.R, c, Sc, lk, liv, &s_x, &s_max);
     if (m >= KH_DD_M) {                // denser than the staging area: general path
@@ -2011,7 +2074,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     hb[it] = 0;
     const uint32_t x = it * KH_CHUNK_THREADS + tid;
     if ((rep_mask >> it) & 1u) {
-      hb[it] = SRC != 1 ? (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc) : (uint32_t)(liv[x] >> 32);
+      hb[it] = (SRC == 0 || SRC == 2) ? (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc) : ((uint32_t)(liv[x] >> 32) & 0x3FFFFFFFu);
       atomicAdd(&cnt[hb[it]], 1u);
       // position + 1 of the first occurrence of a NEW key (SRC 2: the field is already shifted, 0 = the key was in the table)
       if (SRC == 0 && P.mode == KH_DEDUP_FIRST) { const uint32_t ix = (uint32_t)(liv[x] >> 32) + 1u; my_max = ix > my_max ? ix : my_max; }
@@ -2059,7 +2122,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   }
   // ---- publish / look back
   if (tid == 0) {
-    if (SRC != 1 && c < 64) {     // the first 64 chunks vote on the duplicate ratio (same-address atomics are kept off the other 65 K)
+    if ((SRC == 0 || SRC == 2) && c < 64) {     // the first 64 chunks vote on the duplicate ratio (same-address atomics are kept off the other 65 K)
       const unsigned long long mine = ((unsigned long long)(n_c - vote_old) << 32) | vote_rec;     // new distinct keys, records
       const unsigned long long tot = atomicAdd(&P.est[0], mine) + mine;      // < 64 * 2048 records: the low word cannot carry
       const uint32_t sn = (uint32_t)(tot >> 32), sm = (uint32_t)tot;

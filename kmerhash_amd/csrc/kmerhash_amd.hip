@@ -182,6 +182,7 @@ kh_status arena_take(kh_table* t, size_t bytes, void** out) {
   }
   size_t cap = std::max(bytes, size_t(64) << 20);
   void* vp = nullptr;
+  if (getenv("KH_DEBUG_ARENA")) fprintf(stderr, "[kmerhash_amd] arena grows by %.3f GB (block %zu)\n", cap / 1e9, t->blocks.size());
   HIPCHK(pool_alloc(t->device, cap, &vp));
   char* p = static_cast<char*>(vp);
   Block b; b.p = p; b.cap = cap;
@@ -204,6 +205,7 @@ kh_status arena_prepare(kh_table* t, size_t bytes) {
     t->blocks.clear();
   }
   void* p = nullptr;
+  if (getenv("KH_DEBUG_ARENA")) fprintf(stderr, "[kmerhash_amd] arena prepared: %.3f GB (asked %.3f, held %.3f in %zu blocks)\n", std::max(bytes, total) / 1e9, bytes / 1e9, total / 1e9, t->blocks.size());
   HIPCHK(pool_alloc(t->device, std::max(bytes, total), &p));
   Block b; b.p = static_cast<char*>(p); b.cap = std::max(bytes, total);
   t->blocks.push_back(b);
@@ -351,6 +353,7 @@ kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw
   { Launch L(t, name);
     if (src == 0) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 0>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 1) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    else if (src == 3) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 3>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }      // (batch erase: Robin Hood only)
     else { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); } }
   { Launch L(t, "k_fused_totals");
     hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
@@ -515,10 +518,12 @@ inline uint64_t part_buffer_records(uint64_t n, uint32_t PB, bool allow_slack) {
 // stream position of the first pair (pairs fed before it in a streamed insert).  Asynchronous on the table's stream.
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
                           uint32_t vconst, uint64_t n, uint64_t idx_base, uint32_t PB, ulonglong2* tmp, ulonglong2* fin, Partitioned& out,
-                          bool allow_slack = false, int rec12 = 0, const SlackShared* shared = nullptr) {
+                          bool allow_slack = false, int rec12 = 0, const SlackShared* shared = nullptr, bool force_slack = false) {
   const uint32_t nparts = 1u << PB;
   out.slot = 0; out.cursor = nullptr; out.overflow = nullptr; out.rec12 = 0;
-  if (shared || part_buffer_records(n, PB, allow_slack) != n) {
+  // (force_slack: the caller has sized tmp / fin for the fixed slots itself -- (slack_slot(n / 2^PB) << PB) + KH_PART_TILE records each --
+  //  whatever n is: the erase keys of a batch erase, where the histogram sweep would cost more than the partition)
+  if (shared || force_slack || part_buffer_records(n, PB, allow_slack) != n) {
     // ---- histogram-free two-pass partition: hashed keys fill the 2^PB partitions evenly, so every partition
     // gets a fixed slot of mean + 7 sigma records and the passes reserve space with their cursors alone: no histogram sweep
     // over the keys (0.33 ms per 1e8), no offset scan.  Level-1 buckets are the unions of their partitions' slots.
@@ -658,6 +663,11 @@ uint64_t capacity_after(const kh_table* t, uint64_t cap, uint64_t lsize, uint64_
 }
 
 enum { INS_FIRST = 0, INS_UPDATE = 1, INS_PLUS = 2 };
+// Pairs one internal pass takes.  A batch is the reference's SEQUENCE of insert() calls (one doubling decision per call), so cutting it
+// into consecutive passes changes nothing observable; what it bounds is the workspace -- ~58 B per pair of a pass: a k-mer counter's
+// file batch of 1.7e9 k-mers would otherwise ask for a 100 GB arena, whose hipMalloc alone costs 0.7 s (measured, scripts/kc_scale_probe.py).
+const uint64_t g_max_pass = getenv("KH_MAX_PASS_RECORDS") ? std::max<uint64_t>(1024, std::min<uint64_t>(strtoull(getenv("KH_MAX_PASS_RECORDS"), nullptr, 10), 0xFFFFFFF0ull))
+                                                          : (uint64_t(1) << 29);
 bool g_disable_fused = getenv("KH_DISABLE_FUSED_BUILD") != nullptr;   // test hook: force the general path
 
 // second half of an insert: the n pairs have been partitioned (one source per feed); de-dup, capacity decision, build
@@ -942,7 +952,7 @@ kh_status insert_device(kh_table* t, const char* kb, uint32_t kstride, const cha
     // once per insert() call, so peel single calls until at most one is pending
     uint64_t take = n - done;
     if (t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) take = 1;
-    if (take > 0xFFFFFFF0ull) take = 0xFFFFFFF0ull;    // 32-bit record indices
+    if (take > g_max_pass) take = g_max_pass;          // 32-bit record indices; bounded workspace (see g_max_pass)
     t->blk = keep_blk; t->off = keep_off;
     uint64_t nn = 0;
     if (take == 1 && t->lsize >= threshold(t->cur.cap << 1, t->max_lf)) {
@@ -1119,10 +1129,11 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
   if (n && !keys) return fail(t, KH_ERR_INVALID, "null keys");
   if (t->ins.active) return fail(t, KH_ERR_INVALID, "a streamed insert is in progress (kh_insert_end first)");
   HIPCHK(hipSetDevice(t->device));
-  { const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, n ? n : 1, n, n ? n - 1 : 0);
+  { const uint64_t np_ = std::min<uint64_t>(n, g_max_pass);       // (pairs of one internal pass: insert_device)
+    const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, np_ ? np_ : 1, np_, np_ ? np_ - 1 : 0);
     const bool ip = inplace_ok(t, n) && t->lsize + n <= t->max_load;      // in place: no re-layout workspace, bins instead
     kh_status ps = ip ? arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_inplace(t, n))
-                      : arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 58 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (n / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
+                      : arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + np_ * 58 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (np_ / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
     if (ps != KH_OK) return ps; }
   const char* kb = static_cast<const char*>(keys);
   const char* vb = static_cast<const char*>(vals);
@@ -1302,7 +1313,8 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
   if (!keys) return fail(t, KH_ERR_INVALID, "null keys");
   HIPCHK(hipSetDevice(t->device));
   { kh_status ps = inplace_ok(t, n) ? arena_prepare(t, n * 8 + ws_inplace(t, n))
-                                    : arena_prepare(t, n * 8 + ws_rebuild(t->cur.cap) + (size_t(1) << 20));
+                                    : arena_prepare(t, n * 8 + 2 * 8 * ((slack_slot((double)n / (double)std::max<uint64_t>(1, t->cur.cap >> KH_LB)) * std::max<uint64_t>(1, t->cur.cap >> KH_LB)) + KH_PART_TILE + n) +
+                                                       ws_rebuild(t->cur.cap) + (t->cur.cap > KH_L ? (t->cur.cap >> KH_LB) : 1) * 96 + (n / KH_PART_TILE + 4096) * 16 + (size_t(2) << 20));
     if (ps != KH_OK) return ps; }
   const uint64_t* q;
   kh_status st = stage_in<uint64_t>(t, keys, n, where, &q);
@@ -1327,6 +1339,51 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
     t->lsize -= t->hpin[0];
     *n_erased = t->hpin[0];
     return KH_OK;
+  }
+  // ---- Robin Hood batch erase as streaming passes: the erase keys are partitioned by chunk like an insert batch (8-byte
+  // records), and ONE launch re-lays the table out chunk by chunk, dropping every element whose key is among its chunk's erase keys (LDS
+  // fold) -- no probe at random into HBM.  Speculative like the other one-launch forms: a chunk whose elements + erase keys exceed the
+  // staging area, a carry chain or a poll time-out send the batch down the mark + re-layout path below.
+  const uint32_t PBe = t->cur.cap > KH_L ? log2u(t->cur.cap >> KH_LB) : 0u;
+  if (t->kind == KHK_RH && !g_disable_fused_rebuild && !getenv("KH_DISABLE_STREAM_ERASE") && t->cur.cap >= 2 * (uint64_t)KH_L && PBe <= 18 &&
+      t->lsize > 0 && t->lsize <= threshold(t->cur.cap, 0.9f) && n <= 0xFFFFFFF0ull) {
+    const size_t keep_blk = t->blk, keep_off = t->off;
+    // hashed erase keys fill the chunks evenly: histogram-free partition into fixed slots (two passes for more than 2^11 chunks); a
+    // slot that overflows (keys given many times over) is caught by the flag and the mark path takes the batch
+    const bool slack = PBe > 11 && !g_disable_slack;
+    const uint64_t mrec = slack ? (slack_slot((double)n / (double)(uint64_t(1) << PBe)) << PBe) + KH_PART_TILE : n;
+    char *a, *b;
+    TAKE(a, char, mrec * sizeof(KhRec8)); TAKE(b, char, mrec * sizeof(KhRec8));
+    Partitioned R;
+    st = partition_batch(t, reinterpret_cast<const char*>(q), 8, nullptr, 0, 0u, n, 0, PBe, reinterpret_cast<ulonglong2*>(a), reinterpret_cast<ulonglong2*>(b), R, slack, 2, nullptr, slack);
+    if (st != KH_OK) return st;
+    t->part_overflow = R.overflow;
+    KhSlots nw;
+    st = fresh_slots(t, t->cur.cap, nw);
+    if (st != KH_OK) return st;
+    KhFusedParams F;
+    memset(&F, 0, sizeof(F));
+    F.src.rec[0] = R.rec; F.src.off[0] = R.part_off; F.src.n = 1; F.src.merged_off = R.part_off; F.src.slot[0] = R.slot; F.src.cur[0] = R.cursor; F.src.rec12 = 2;
+    F.PB = PBe; F.mode = KH_DEDUP_ERASE;
+    F.R.Old = t->cur; F.R.PB = PBe;
+    FusedRun run;
+    { kh_status fs = launch_fused(t, 3, F, nw, PBe, "k_erase_fused", &run); t->part_overflow = nullptr; if (fs != KH_OK) return fs; }
+    const uint32_t* ff = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 64);
+    bool bad = R.overflow && (uint32_t)t->hpin[30];
+    for (int i = 0; i < KH_NFLAGS; ++i) bad = bad || ff[i] != 0;
+    const uint64_t placed = t->hpin[0];
+    if (!bad && placed <= t->lsize) {
+      KhSlots old = t->cur;
+      t->cur = nw;
+      retire_slots(t, old);
+      *n_erased = t->lsize - placed;
+      t->lsize = placed;
+      return KH_OK;
+    }
+    if (getenv("KH_DEBUG_FUSED"))
+      fprintf(stderr, "[kmerhash_amd] fused erase rejected: placed %llu size %llu flags=%u %u %u %u %u\n", (unsigned long long)placed, (unsigned long long)t->lsize, ff[0], ff[1], ff[2], ff[3], ff[4]);
+    retire_slots(t, nw);
+    t->blk = keep_blk; t->off = keep_off;
   }
   unsigned long long* cnt;
   TAKE(cnt, unsigned long long, 1);

@@ -442,7 +442,7 @@ def test_bulk_build_into_empty_table_fused_path(oracle, kname, cls, kind, hname,
 def test_one_launch_relayouts_of_a_robin_hood_table(oracle, hname, hid):
     """the re-layouts of a non-empty RH table take the one-launch kernels and stay bit-exact: a second batch (k_insert_fused:
     table elements and batch records folded in LDS; 10 % of the batch repeats keys of the table, 3 % repeats itself), an erase
-    (k_rebuild_fused at equal capacity: home bucket from the info byte), a doubling rehash and a reserve"""
+    (k_erase_fused at equal capacity: home bucket from the info byte, erase keys folded in LDS), a doubling rehash and a reserve"""
     n = 380_000          # 200 000 in the table + 200 000 records (180 000 new): predicted and actual capacity are both 2^19
     keys = W.distinct_u64(n, seed=31)
     if hname == "identity":
@@ -461,7 +461,8 @@ def test_one_launch_relayouts_of_a_robin_hood_table(oracle, hname, hid):
     check_state(g, o, 0)
     g.profile_reset()
     assert g.erase(dev(keys[100_000:180_000])) == o.erase(keys[100_000:180_000]) == 80_000
-    assert "k_rebuild_fused" in g.profile() and "k_chunk_place" not in g.profile(), g.profile()
+    # (the erase keys are partitioned by chunk and dropped inside the one-launch re-layout: no random-access mark pass)
+    assert "k_erase_fused" in g.profile() and "k_erase_mark" not in g.profile() and "k_chunk_place" not in g.profile(), g.profile()
     check_state(g, o, 0)
     g.profile_reset()
     g.rehash(2 * g.capacity()); o.rehash(2 * o.capacity())
@@ -1247,4 +1248,53 @@ def test_reducer_plus_class_restart_counts_once():
     sk, sv = g.sorted_items()
     uk, cnt = np.unique(np.concatenate([uni, batch]), return_counts=True)
     assert np.array_equal(sk, uk) and np.array_equal(sv, cnt.astype(np.uint32))
+    g.close()
+
+
+def test_batch_erase_streaming_form_and_its_fall_back(oracle, monkeypatch):
+    """a large Robin Hood batch erase partitions its keys by chunk and drops them inside the one-launch re-layout
+    (k_erase_fused).  Hits, misses, keys given twice, keys of a bimolecule table by their other strand; an erase batch too dense for
+    the staging area (elements + erase keys of a chunk >= 2048) falls back to the mark + re-layout path; both equal the oracle."""
+    n = 1_500_000
+    keys = W.distinct_u64(n, seed=41); vals = np.arange(n, dtype=np.uint32)
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8); o = oracle.OracleTable(0, 128, 0.35, 0.8)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals)
+    e1 = np.concatenate([keys[:200_000], W.distinct_u64(50_000, seed=99), keys[:30_000]])       # hits, misses, repeats
+    e1 = e1[W.shuffle_perm(len(e1), 2)]
+    g.profile_enable(True)
+    assert g.erase(dev(e1)) == o.erase(e1) == 200_000
+    p = g.profile()
+    assert "k_erase_fused" in p and "k_erase_mark" not in p, p
+    check_state(g, o, 0)
+    check_queries(g, o, np.concatenate([keys[:5000], keys[300_000:305_000]]))
+    # dense: erase (almost) everything -- ~1270 elements + ~1270 erase keys per chunk do not fit the staging area
+    g.profile_reset()
+    e2 = keys[200_000:1_450_000]
+    assert g.erase(dev(e2)) == o.erase(e2) == len(e2)
+    p = g.profile()
+    assert "k_erase_fused" in p and "k_erase_mark" in p, p             # tried, rejected, marked + re-laid out
+    check_state(g, o, 0)
+    g.close()
+    # the old path by itself (test hook) gives the same table
+    monkeypatch.setenv("KH_DISABLE_STREAM_ERASE", "1")
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8); o = oracle.OracleTable(0, 128, 0.35, 0.8)
+    g.insert(dev(keys), dev(vals)); o.insert(keys, vals)
+    g.profile_enable(True)
+    assert g.erase(dev(e1)) == o.erase(e1)
+    assert "k_erase_mark" in g.profile() and "k_erase_fused" not in g.profile()
+    check_state(g, o, 0)
+    g.close()
+    monkeypatch.delenv("KH_DISABLE_STREAM_ERASE")
+    # key transform: erase by the other strand
+    k = 21
+    kk = W.distinct_u64(400_000, seed=5) & np.uint64((1 << (2 * k)) - 1)
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash="farm"); g.set_key_transform(k)
+    o = oracle.OracleTable(0, 128, 0.35, 0.8, 3, 43); o.set_key_transform(k)
+    vv = np.arange(len(kk), dtype=np.uint32)
+    assert g.insert(dev(kk), dev(vv)) == o.insert(kk, vv)
+    er = np.concatenate([_revcomp(kk[:20_000], k), kk[150_000:155_000]])          # (~100 erase keys next to ~1560 elements per chunk)
+    g.profile_enable(True)
+    assert g.erase(dev(er)) == o.erase(er)
+    assert "k_erase_fused" in g.profile() and "k_erase_mark" not in g.profile()
+    check_state(g, o, 0)
     g.close()
