@@ -42,6 +42,7 @@ def parse(argv):
     ap.add_argument("--cycle", action="store_true", help="run the count / find / erase / count query cycle after the inserts")
     ap.add_argument("--sample-ratio", type=int, default=100, help="queries = every s-th k-mer of the rank's input (BenchmarkKmerIndex -q sampling)")
     ap.add_argument("--hll-reserve", action="store_true", help="pre-size the table from a HyperLogLog estimate per batch instead of doubling under load")
+    ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event times of the local table (kh_profile_*) in the JSON line")
     ap.add_argument("--verify", action="store_true", help="check size, total count and a sample of 10^5 k-mer counts against the prediction from the read positions")
     ap.add_argument("--out", default="", help="write this rank's (k-mer, count) tuples (BenchmarkKmerCounter.cpp:1022-1211)")
     return ap.parse_args(argv)
@@ -142,17 +143,28 @@ def run_rank(args):
             torch.cuda.synchronize()
 
     caps = []
+    if args.profile:
+        be.table.profile_enable(True)
     sync()
     t0 = time.perf_counter()
+    t_batch = []
     for i in range(args.batches):
+        tb = time.perf_counter()
         kc.add_fastq(dfq[cuts[i]:cuts[i + 1]])
         caps.append(be.table.capacity())
+        if args.profile:
+            torch.cuda.synchronize()
+            t_batch.append(round((time.perf_counter() - tb) * 1e3, 2))
     sync()
     t_ins = time.perf_counter() - t0
     total_local = kc.total_kmers
     size_after = kc.size()
     res = {"kmers_local": total_local, "capacity_per_batch_rank0": caps, "distinct_global": size_after,
            "insert_s": t_ins, "phases_ms_rank0": {k: round(v, 3) for k, v in st.timings().items()}, "batch_sizing": batch_note}
+    if args.profile:
+        res["batch_ms"] = t_batch
+        res["insert_kernels_ms"] = {k: round(v[1], 2) for k, v in sorted(be.table.profile().items(), key=lambda kv: -kv[1][1])}
+        be.table.profile_reset()
 
     ok = True
     if args.verify:

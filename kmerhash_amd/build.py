@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "kmerhash_amd.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "kh_kernels.h"), os.path.join(HERE, "..", "include", "kmerhash_amd", "kh_hash.h"),
         os.path.join(HERE, "..", "include", "kmerhash_amd.h")]
-LIB = os.path.join(HERE, "libkmerhash_amd.so")
+# KH_LIB_SUFFIX: experiment builds next to the product (libkmerhash_amd<suffix>.so, built with KH_EXTRA_FLAGS) for A/B runs on one box
+LIB = os.path.join(HERE, "libkmerhash_amd%s.so" % os.environ.get("KH_LIB_SUFFIX", ""))
 RES = os.path.join(HERE, "kernel_resources.json")      # per-kernel registers / LDS / occupancy reported by the compiler
 
 

@@ -27,9 +27,13 @@
 #define KH_PART_THREADS 512
 #define KH_PART_MAXPER 4            // digits per lane in the scatter's scan: nb <= 2048 bins
 #endif
+#ifndef KH_PART_ITEMS
 #define KH_PART_ITEMS 16
+#endif
 #define KH_PART_TILE (KH_PART_THREADS * KH_PART_ITEMS)   // 8192 records per partition tile: ONE reservation per (tile, digit)
+#ifndef KH_PART_STAGE
 #define KH_PART_STAGE 4096       // records staged in LDS at a time: the tile is streamed out in TILE/STAGE rounds
+#endif
 #define KH_NONE 0xFFFFFFFFFFFFFFFFull
 #define KH_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
@@ -658,13 +662,22 @@ __device__ __forceinline__ void kh_rec_get(const KhRec8& r, uint64_t& key, unsig
 template <int RK> struct KhRecOf { typedef ulonglong2 type; };
 template <> struct KhRecOf<1> { typedef KhRec12 type; };
 template <> struct KhRecOf<2> { typedef KhRec8 type; };
+#ifdef KH_PART_OCC3
+// experiment: three workgroups per CU for the 12- and 8-byte record kinds (80 VGPRs, <= 53 KB of LDS: 3072 / 4096 records staged)
+#define KH_PART_LB(RK) __launch_bounds__(KH_PART_THREADS, (RK) ? 6 : 4)      // (HIP: second argument = waves per SIMD)
+#define KH_PART_STAGE_OF(RK) ((RK) == 1 ? 3072u : (uint32_t)KH_PART_STAGE)
+#else
+#define KH_PART_LB(RK) __launch_bounds__(KH_PART_THREADS)
+#define KH_PART_STAGE_OF(RK) ((uint32_t)KH_PART_STAGE)
+#endif
 template <int HASH, int RK>
-__global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P) {
+__global__ KH_PART_LB(RK) void k_part_scatter(KhPartParams P) {
   constexpr bool R12 = RK != 0;                   // (no stream positions in the records)
+  constexpr uint32_t STAGE = KH_PART_STAGE_OF(RK);
   typedef typename KhRecOf<RK>::type Rec;
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
-  __shared__ Rec lrec[KH_PART_STAGE];
-  __shared__ uint16_t ld[KH_PART_STAGE];
+  __shared__ Rec lrec[STAGE];
+  __shared__ uint16_t ld[STAGE];
   __shared__ uint32_t wtot[KH_PART_THREADS / 64];
   const uint32_t nb = P.nb;
   uint32_t* hist = kh_dyn_smem;                 // [nb] counts, then reused as running fill
@@ -762,7 +775,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
     }
   }
   __syncthreads();
-  for (uint32_t r0 = 0; r0 < d.len; r0 += KH_PART_STAGE) {
+  for (uint32_t r0 = 0; r0 < d.len; r0 += STAGE) {
     if (r0) __syncthreads();                    // the previous round has been streamed out
 #pragma unroll
     for (int j = 0; j < KH_PART_ITEMS; ++j) {
@@ -770,7 +783,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
       if (i < d.len) {
         const uint32_t dg = dr[j] >> 16;
         const uint32_t s = loff[dg] + (dr[j] & 0xFFFFu) - r0;     // position in the tile's digit order, relative to this round
-        if (s < KH_PART_STAGE) { kh_rec_set(lrec[s], key[j], iv[j]); ld[s] = (uint16_t)dg; }
+        if (s < STAGE) { kh_rec_set(lrec[s], key[j], iv[j]); ld[s] = (uint16_t)dg; }
       }
     }
     if (r0 == 0) {
@@ -781,7 +794,7 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_scatter(KhPartParams P
       }
     }
     __syncthreads();
-    const uint32_t rl = d.len - r0 < KH_PART_STAGE ? d.len - r0 : KH_PART_STAGE;
+    const uint32_t rl = d.len - r0 < STAGE ? d.len - r0 : STAGE;
     for (uint32_t s = tid; s < rl; s += KH_PART_THREADS) {
       const uint32_t dd = ld[s];
       const uint64_t pos = gbase[dd] + (r0 + s - loff[dd]);

@@ -17,7 +17,7 @@ for c in TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA_RDREQ_sum TCC_REQ_sum
 done
 echo "counters:$WANT"
 for c in $WANT; do
-  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${c}_$TAG -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_${c}_$TAG.log 2>&1 || echo "pass $c failed"
+  timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${c}_$TAG -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/pmc_${c}_$TAG.log 2>&1 || echo "pass $c failed"
 done
 python3 - "$TAG" "$OUT" $WANT <<'PY'
 import sys, glob, csv, collections

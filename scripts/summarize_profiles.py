@@ -16,6 +16,9 @@ STREAMING = ("k_part_scatter", "k_part_hist", "k_build_fused", "k_dedup", "k_chu
 ks = glob.glob("gpurun_out/prof_%s/*/*_kernel_stats.csv" % tag)
 if ks:
     shutil.copy(ks[0], "profiles/%s_kernel_stats.csv" % tag)
+kp = glob.glob("gpurun_out/prof_%s_phases/*/*_kernel_stats.csv" % tag)      # bench.py WITH its informational legs (erase, count, W1, LP ...)
+if kp:
+    shutil.copy(kp[0], "profiles/%s_phases_kernel_stats.csv" % tag)
 res = {}
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     fs = glob.glob("gpurun_out/%s_%s/*/*counter_collection.csv" % (name, tag))
