@@ -554,6 +554,7 @@ def run_rank(args):
         e1.record()
         if distributed:
             _, fvals, ffound = t.find(dq)
+            t.synchronize()                        # (find only queues its work; this also raises if any rank's local part failed)
             n_hit = int(ffound.sum().item())
         else:
             fk, fv = table.find(dq)

@@ -1,18 +1,20 @@
 // kh_kernels.h -- gfx950 device code of libkmerhash_amd (included once by kmerhash_amd.hip).
 //
-// Design: the table is SoA in HBM (keys u64[cap], vals u32[cap], info u8[cap]) and is
-// processed in CHUNKS of KH_L = 2^KH_LB consecutive home buckets.  A mutating batch never probes HBM
-// at random: the batch is radix-partitioned by (bit-reversed) chunk id with coalesced streaming
-// passes, each partition is de-duplicated first-value-wins inside LDS, and every chunk of the new
-// table is then laid out in its canonical Robin Hood order (elements sorted by home bucket, slot =
-// max(home, previous slot + 1)) by one workgroup that histograms the chunk's home buckets in LDS and
-// runs a max-plus scan over them; run-over between chunks is a (max,+) carry.  Bulk builds into an
-// empty table do all of that after the partition in ONE kernel (k_build_fused, one-deep carry
-// look-back); the same kernel re-lays out a non-empty Robin Hood table from the table itself (SRC 1:
-// erase, rehash) and merges a batch into it (SRC 2: table elements + batch records folded in LDS).
-// The general path is k_dedup -> k_chunk_count -> k_chunk_carry -> k_chunk_place.
-// Read-only batches (find/count) and erase marking probe the table directly, one query per lane.
-//
+// Design.  The table is ONE array of 16-byte slots in HBM, {u64 key, u32 value, u32 info} per bucket (KhSlot; the low
+// byte of `info` is the reference's info byte, bit 8 the erase mark of a batch erase on its fall-back path), read and written with one
+// dwordx4 access, and is processed in CHUNKS of KH_L = 2^KH_LB consecutive home buckets (32 KB of table).
+//   * A large mutating batch never probes HBM at random: it is radix-partitioned by (bit-reversed) chunk id with coalesced streaming
+//     passes (k_part_scatter: 16-, 12- or 8-byte records; histogram-free into fixed slots when a sample finds no duplicates), and every
+//     chunk of the new table is laid out in its canonical Robin Hood order (elements sorted by home bucket, slot = max(home, previous
+//     slot + 1)) by one workgroup that histograms the chunk's home buckets in LDS and runs a (max,+) scan over them; run-over between
+//     chunks is a (max,+) carry with a one-deep look-back.  k_build_fused does all of that in ONE launch, from partition records
+//     (SRC 0: bulk build into an empty table), from the table itself (SRC 1: rehash / reserve / the erase fall-back), from both
+//     folded together in LDS (SRC 2: insert into a non-empty table) or from the table minus the chunk's erase keys (SRC 3: batch
+//     erase).  The general path is k_dedup -> k_chunk_count -> k_chunk_carry -> k_chunk_place.
+//   * Batches of <= 16 keys are applied in place by one lane (k_small_batch), mid-size batches in place by one lane per region of
+//     512 slots (k_ip_bin / k_ip_apply / k_ip_serial).
+//   * Read-only batches (k_find: find, count) probe the table one 64-byte SECTOR (4 aligned slots) at a time, four queries per lane
+//     in flight, and compact their hits inside the same launch (wave ballots + decoupled look-back over the tiles).
 // Wave64 everywhere; no MFMA (integer/indexing path).
 #pragma once
 #include <hip/hip_runtime.h>

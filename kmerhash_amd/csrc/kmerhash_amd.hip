@@ -2,12 +2,14 @@
 //
 // Host logic restates the reference's *observable* contract (sizes, float load thresholds, the
 // doubling/halving rules, first-value-wins) around the chunked GPU kernels of kh_kernels.h:
-//   insert  : partition batch -> LDS de-dup + membership test (k_dedup) -> exact capacity decision
-//             (hashmap_robinhood.hpp:530 rule, evaluated in closed form) -> chunk rebuild into a fresh
-//             buffer (count -> carry scan -> place).  The old buffer stays valid until the new one is
-//             complete, so a failing batch (probe distance >= 128) leaves the table untouched.
-//   erase   : RH marks hits in a bitmask and rebuilds without them; LP writes tombstones in place.
-//   find/count : direct probing, one query per lane.
+//   insert  : sample -> partition the batch by chunk -> one-launch build (k_build_fused; speculates that the capacity the
+//             reference's rule yields is the predicted one) or, when a speculation fails, LDS de-dup + membership test (k_dedup)
+//             -> exact capacity decision (hashmap_robinhood.hpp:530 rule, evaluated in closed form) -> chunk rebuild into a
+//             fresh buffer.  The old buffer stays valid until the new one is complete, so a failing batch (probe distance >= 128)
+//             leaves the table untouched.  Batches of up to 16 keys and mid-size batches are applied in place.
+//   erase   : RH partitions the erase keys by chunk and drops them inside a one-launch re-layout (fall-back: mark hits, re-lay
+//             out without them); LP writes tombstones in place.
+//   find/count : sector probing with in-launch compaction (k_find).
 #include "kh_kernels.h"
 #include "../../include/kmerhash_amd.h"
 

@@ -1,8 +1,11 @@
 #!/bin/bash
 # usage (GPU box, repo root): bash scripts/gpu_round_check.sh <tag>
-# GPU test suite, then bench.py through its launcher (N=1), the loud failure of --gpus 2 on a one-GPU box, and the N>1 code
-# path rehearsed with a single RCCL rank.  Steps are joined with && : nothing runs after a failed GPU step.
-TAG=${1:-r2}
+# GPU test suite (it holds the forced-collectives runs of BOTH sharded layers over RCCL: tests/cpp/test_dist.cpp and
+# tests/test_gpu_dist_nccl.py), then bench.py through its launcher (N=1; the JSON line carries the five phases for both tables, the
+# host-inclusive pass, W1, the second batch and configs[2]), the loud failure of --gpus 2 on a one-GPU box, and the N>1 code path of
+# bench.py rehearsed with a single RCCL rank (every collective executed as a self-exchange).  Steps are joined with && : nothing runs
+# after a failed GPU step.
+TAG=${1:-r3}
 OUT=gpurun_out
 mkdir -p $OUT
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $OUT/gputest_$TAG.log 2>&1 && \
