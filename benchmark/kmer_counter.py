@@ -44,7 +44,9 @@ def parse(argv):
     ap.add_argument("--hll-reserve", action="store_true", help="pre-size the table from a HyperLogLog estimate per batch instead of doubling under load")
     ap.add_argument("--profile", action="store_true", help="per-kernel HIP-event times of the local table (kh_profile_*) in the JSON line")
     ap.add_argument("--verify", action="store_true", help="check size, total count and a sample of 10^5 k-mer counts against the prediction from the read positions")
-    ap.add_argument("--out", default="", help="write this rank's (k-mer, count) tuples (BenchmarkKmerCounter.cpp:1022-1211)")
+    ap.add_argument("--out", default="", help="write this rank's (k-mer, count) tuples (BenchmarkKmerCounter.cpp:1022-1211): 8 + 2 bytes each like the "
+                                               "reference, whose CountType is uint16_t (:184) -- the table's 32-bit counts are truncated to 16 bits in the FILE "
+                                               "(= the value the reference's wrapping counter would hold); find / count / --verify use the 32-bit counts")
     return ap.parse_args(argv)
 
 

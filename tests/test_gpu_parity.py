@@ -1298,3 +1298,71 @@ def test_batch_erase_streaming_form_and_its_fall_back(oracle, monkeypatch):
     assert "k_erase_fused" in g.profile() and "k_erase_mark" not in g.profile()
     check_state(g, o, 0)
     g.close()
+
+
+@pytest.mark.parametrize("kname,cls,kind", KINDS)
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_sequences_with_reducer_plus_and_aborts(oracle, kname, cls, kind, seed):
+    """random sequences mixing Reducer = std::plus inserts (one call / streamed, repeatable or not, with and without values), first-wins
+    inserts, batch erases and ABORTED streamed inserts.  Key set, capacity and info bytes against the oracle (fed the same key batches);
+    values against a dictionary model (wrapping 32-bit sums).  Covers the deferred (slot, sum) lists of k_dedup / k_apply_plus, the
+    in-place and small-batch paths, the streaming batch erase and kh_insert_abort in whatever state the sequence reaches them."""
+    rng = np.random.default_rng(1000 * seed + kind)
+    uni = W.distinct_u64(300_000, seed=50 + seed)
+    g = cls(128, 0.35, 0.8); o = oracle.OracleTable(kind, 128, 0.35, 0.8)
+    model = {}
+    for step in range(30):
+        op = int(rng.integers(0, 6))
+        m = int(rng.choice([1, 7, 300, 5_000, 60_000, 250_000]))
+        ks = uni[rng.integers(0, len(uni), m)]
+        vs = rng.integers(0, 2**32, m, dtype=np.uint32)
+        if op <= 1:                                              # counting / summing insert, one call
+            use_v = bool(rng.integers(0, 2))
+            g.insert_reduce_plus(dev(ks), dev(vs) if use_v else None)
+            o.insert(ks, vs)
+            for k, v in zip(ks.tolist(), vs.tolist() if use_v else [1] * m):
+                model[k] = (model.get(k, 0) + v) & 0xFFFFFFFF
+        elif op == 2:                                            # the same, streamed; sometimes aborted half-way
+            cuts = sorted(set([0, m] + [int(x) for x in rng.integers(0, m + 1, 3)]))
+            rep = bool(rng.integers(0, 2))
+            abort = rng.random() < 0.3
+            try:
+                g.insert_begin(m, reduce_plus=True, repeatable=rep)
+                for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                    if abort and i == len(cuts) - 2:
+                        break
+                    g.insert_feed(dev(ks[a:b]))
+                if abort:
+                    g.insert_abort()
+                else:
+                    g.insert_end()
+            except kh.KhRetry:
+                assert rep and not abort
+                g.insert_begin(m, reduce_plus=True)
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    g.insert_feed(dev(ks[a:b]))
+                g.insert_end()
+            if not abort:
+                o.insert(ks, vs)
+                for k in ks.tolist():
+                    model[k] = (model.get(k, 0) + 1) & 0xFFFFFFFF
+        elif op == 3:                                            # first value wins
+            g.insert(dev(ks), dev(vs)); o.insert(ks, vs)
+            for k, v in zip(ks.tolist(), vs.tolist()):
+                model.setdefault(k, v)
+        elif op == 4:
+            assert g.erase(dev(ks)) == o.erase(ks)
+            for k in ks.tolist():
+                model.pop(k, None)
+        else:
+            fk, fv = g.find(dev(ks))
+            fk = host(fk, np.uint64); fv = host(fv, np.uint32)
+            exp = [(k, model[k]) for k in ks.tolist() if k in model]
+            assert fk.tolist() == [k for k, _ in exp] and fv.tolist() == [v for _, v in exp]
+        assert (g.size(), g.capacity()) == (o.size(), o.capacity()) == (len(model), o.capacity()), (step, op, m)
+        if kind == 0:
+            assert np.array_equal(g.export_info(), o.export_info()), (step, op, m)
+        sk, sv = g.sorted_items()
+        mk = np.array(sorted(model), dtype=np.uint64)
+        assert np.array_equal(sk, mk) and np.array_equal(sv, np.array([model[k] for k in mk.tolist()], dtype=np.uint32)), (step, op, m)
+    g.close()
