@@ -1069,6 +1069,7 @@ __device__ __forceinline__ uint32_t kh_wave_max(uint32_t v) {
   return v;
 }
 
+#define KH_UPD_APPLIED 0x80000000u
 enum { KH_DEDUP_FIRST = 0, KH_DEDUP_LAST = 1, KH_DEDUP_PLUS = 2, KH_DEDUP_ERASE = 3 };     // (ERASE: k_build_fused<.., 3>, no fold)
 #define KH_DD_M 2048u            // records staged per de-dup round
 
@@ -1221,7 +1222,11 @@ struct KhDedupParams {
   // have to discard the attempt: a histogram-free partition that overflowed, a failing re-layout).  Their (slot index, sum) pairs
   // are listed from the END of the partition's output region downwards (nk[end - 1 - j] = slot, nv[end - 1 - j] = sum; new keys
   // + existing keys <= records of the partition, so the two lists never meet); k_apply_plus adds them once the attempt stands
-  uint32_t* cnt_upd;                                             // [nparts]
+  uint32_t* cnt_upd;                                             // [nparts]; bit 31 (KH_UPD_APPLIED): this partition's sums are in the table already
+  // != 0: nothing can discard this attempt before the table is re-laid out (exact partition offsets, no repeatable streamed insert):
+  // a partition that needs ONE class (nearly all do) adds its sums right here, as part of its membership probes, and sets
+  // KH_UPD_APPLIED; the list is written all the same -- it is what takes the sums back if the re-layout fails
+  int plus_immediate;
   unsigned long long* max_idx_plus1;                             // max (first-occurrence index + 1) over new keys
   KhSlots T; KhSeed seed;
   // speculative fusion of the chunk-count step (empty table, one partition == one chunk of capacity count_cap):
@@ -1383,7 +1388,10 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
             at = kh_find_pos<KIND>(P.T.s, mask, h & mask, key, &cur_val, P.seed.xk);
           }
           if (P.mode == KH_DEDUP_LAST) { if (at != KH_NONE) P.T.s[at].val = (uint32_t)iv; }   // kh_update's assign pass: store the LAST value
-          else if (P.mode == KH_DEDUP_PLUS && at != KH_NONE) upd = true;      // deferred: (slot, sum) listed, applied by k_apply_plus
+          else if (P.mode == KH_DEDUP_PLUS && at != KH_NONE) {
+            upd = true;                                                    // (slot, sum) listed for k_apply_plus ...
+            if (P.plus_immediate && R == 1) P.T.s[at].val = cur_val + (uint32_t)iv;      // ... or added at once (one lane per distinct key: no race)
+          }
           else emit = at == KH_NONE;
         }
         if (plus_live) {       // (wave-uniform)
@@ -1412,7 +1420,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
   __syncthreads();
   if (tid == 0) {
     P.cnt_new[q] = out_count;
-    if (plus_live) P.cnt_upd[q] = upd_count;
+    if (plus_live) P.cnt_upd[q] = upd_count | ((P.plus_immediate && R == 1) ? KH_UPD_APPLIED : 0u);
     if (out_count) atomicMax(P.max_idx_plus1, (unsigned long long)max_idx);
   }
   if (fuse) {      // what k_chunk_count would produce for this chunk
@@ -1438,11 +1446,14 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
 // the deferred half of a KH_DEDUP_PLUS pass over a non-empty table: every key the table already held gets the sum k_dedup listed for
 // it (sign = +1), or loses it again (sign = -1: the re-layout that followed failed and the table must read as before).  Every slot
 // appears in at most one list entry (a key belongs to one partition and one class): no race.
+// sign +1 skips the partitions whose sums k_dedup added itself (KH_UPD_APPLIED); sign -1 takes back every listed sum.
 __global__ void k_apply_plus(KhSlot* __restrict__ slots, const uint64_t* __restrict__ merged_off, const uint32_t* __restrict__ cnt_upd,
                              const uint64_t* __restrict__ nk, const uint32_t* __restrict__ nv, uint32_t nparts, int sign) {
   for (uint32_t q = blockIdx.x; q < nparts; q += gridDim.x) {
     const uint64_t end = merged_off[q + 1];
-    const uint32_t c = cnt_upd[q];
+    const uint32_t cw = cnt_upd[q];
+    if (sign > 0 && (cw & KH_UPD_APPLIED)) continue;
+    const uint32_t c = cw & ~KH_UPD_APPLIED;
     for (uint32_t j = threadIdx.x; j < c; j += blockDim.x) {
       const uint64_t at = nk[end - 1 - j];
       const uint32_t d = nv[end - 1 - j];

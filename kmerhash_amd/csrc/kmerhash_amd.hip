@@ -877,6 +877,9 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   const bool plus_live = mode == INS_PLUS && t->lsize > 0;
   D.cnt_upd = nullptr;
   if (plus_live) TAKE(D.cnt_upd, uint32_t, R.nparts);
+  // with exact partition offsets nothing can discard the attempt before the re-layout: the sums are added inside k_dedup (its
+  // membership probes have the slot in hand) and the list only serves to take them back should the re-layout fail
+  D.plus_immediate = (plus_live && t->part_overflow == nullptr && !getenv("KH_DISABLE_PLUS_IMMEDIATE")) ? 1 : 0;
   if (t->lsize > 0 && t->cur.cap > KH_L && !getenv("KH_DISABLE_XCD_GROUP")) {
     // partitions are cut for cap_u, the probes go to the (smaller) current table: 2^(PB - k) consecutive partitions share one of its chunks
     const uint32_t k_tab = log2u(t->cur.cap >> KH_LB);
@@ -1094,7 +1097,7 @@ kh_status insert_inplace(kh_table* t, const char* kb, uint32_t kstride, const ch
   TAKE(zpre, char, 64);
   HIPCHK(hipMemsetAsync(zpre, 0, 64, t->stream));
   D.max_idx_plus1 = reinterpret_cast<unsigned long long*>(zpre); D.flags = reinterpret_cast<uint32_t*>(zpre + 32);
-  if (mode == INS_PLUS) TAKE(D.cnt_upd, uint32_t, R.nparts);
+  if (mode == INS_PLUS) { TAKE(D.cnt_upd, uint32_t, R.nparts); D.plus_immediate = getenv("KH_DISABLE_PLUS_IMMEDIATE") ? 0 : 1; }      // (nothing discards an in-place batch)
   { Launch L(t, "k_dedup");
     KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_dedup<KIND, HASH>), dim3(R.nparts), dim3(KH_CHUNK_THREADS), 0, t->stream, D)); }
   if (mode == INS_PLUS) {      // sums of the keys the table already holds (listed by k_dedup; nothing can discard an in-place batch)
