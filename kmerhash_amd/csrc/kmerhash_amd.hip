@@ -706,7 +706,11 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
       hipLaunchKernelGGL(k_sample_dups, dim3(KH_SAMPLE_N / 256), dim3(256), 0, t->stream, kbase, kstride, n, sset, dups); }
     HIPCHK(hipMemcpyAsync(t->hpin + 31, dups, 4, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
-    if ((uint32_t)t->hpin[31] >= 8u) { first_attempt = 1; dup_heavy = true; }
+    // ANY duplicate among the 65536 sampled keys sends the batch down the exact path: the fixed slots are sized for partition counts
+    // that are Poisson in the number of RECORDS, and already a mean multiplicity of 1.5 (a k-mer counter's file batch at low coverage:
+    // ~7 duplicate pairs in the sample, birthday-bound) widens them enough to overflow a slot somewhere among 2^19 partitions --
+    // measured: every such batch paid a discarded 7.5 ms partition attempt; the histogram sweep of the exact path costs 2.5 ms
+    if ((uint32_t)t->hpin[31] >= 1u) { first_attempt = 1; dup_heavy = true; }
     t->batch_nodup = (uint32_t)t->hpin[31] == 0u;
     t->blk = keep_blk; t->off = keep_off;
   } else first_attempt = 1;
@@ -1588,7 +1592,7 @@ kh_status kh_insert_feed(kh_table* t, const void* keys, const void* vals, uint64
       HIPCHK(hipStreamSynchronize(t->stream));
       t->ins.nodup = (uint32_t)t->hpin[31] == 0u;
       // a repeatable insert of (nearly) duplicate-free pieces: histogram-free partition into slots all pieces share
-      t->ins.slack = t->ins.repeatable && (uint32_t)t->hpin[31] < 8u && part_buffer_records(t->ins.n_total, t->ins.PB, true) != t->ins.n_total;
+      t->ins.slack = t->ins.repeatable && (uint32_t)t->hpin[31] == 0u && part_buffer_records(t->ins.n_total, t->ins.PB, true) != t->ins.n_total;
     }
     if (t->ins.S.n == 0 && t->ins.repeatable) {       // buffers of the chosen layout
       const uint64_t nt = t->ins.n_total;
