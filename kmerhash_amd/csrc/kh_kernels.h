@@ -607,7 +607,7 @@ __device__ __forceinline__ KhTile kh_get_tile(const KhPartParams& P, uint32_t t)
   return d;
 }
 
-template <int HASH>
+template <int HASH, bool REC8 = false>      // REC8: rec_in holds 8-byte keys (second level of a counting insert's exact partition)
 __global__ __launch_bounds__(KH_PART_THREADS) void k_part_hist(KhPartParams P) {
   extern __shared__ __align__(16) uint32_t kh_dyn_smem[];
   uint32_t* hist = kh_dyn_smem;
@@ -633,7 +633,8 @@ __global__ __launch_bounds__(KH_PART_THREADS) void k_part_hist(KhPartParams P) {
       cur_seg = d.seg;
     }
     for (uint32_t i = tid; i < d.len; i += KH_PART_THREADS) {
-      uint64_t key = P.rec_in ? P.rec_in[d.beg + i].x : *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
+      uint64_t key = P.rec_in ? (REC8 ? reinterpret_cast<const uint64_t*>(P.rec_in)[d.beg + i] : P.rec_in[d.beg + i].x)
+                              : *reinterpret_cast<const uint64_t*>(P.kbase + (d.beg + i) * P.kstride);
       uint32_t q = kh_part_q(kh_hash64<HASH>(key, P.seed), P.PB);
       atomicAdd(&hist[(q >> P.shift) & (nb - 1)], 1u);
     }

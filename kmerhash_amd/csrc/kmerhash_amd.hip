@@ -567,7 +567,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     out.slot = slot; out.cursor = cur2; out.overflow = ovf; out.rec12 = rec12;
     return KH_OK;
   }
-  if (rec12 == 1 || (rec12 == 2 && PB > 18)) return fail(t, KH_ERR_HIP, "internal: record kind not available with exact offsets");
+  if (rec12 == 1) return fail(t, KH_ERR_HIP, "internal: record kind not available with exact offsets");
   ulonglong2* ar = nullptr; ulonglong2* br = fin;
   const uint32_t B1 = PB <= 11 ? PB : (PB + 1) / 2, B2 = PB - B1;
   const uint32_t nb1 = 1u << B1, nb2 = 1u << B2;
@@ -636,7 +636,8 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
   Q.shift = 0; Q.nb = nb2; Q.counts = counts2; Q.cursor = cur2; Q.orec = br;
   if (!full_hist) {
     { Launch L(t, "k_part_hist");
-      KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); }
+      if (rec12 == 2) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH, true>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); }
+      else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_hist<HASH>), dim3(std::min<uint32_t>(max_tiles, 1024)), dim3(KH_PART_THREADS), nb2 * 4, t->stream, Q)); } }
     { Launch L(t, "k_scan");
       hipLaunchKernelGGL(k_scan_u32_to_u64, dim3(1), dim3(KH_SCAN_THREADS), 0, t->stream, counts2, (uint64_t)nparts, off2); }
   }
@@ -724,7 +725,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     // a counting insert (Reducer = std::plus, every value 1) of a batch the sample found heavy in duplicates -- the k-mer counter's
     // batches: the records are the keys alone (8 bytes: neither value nor position is needed), and the general path takes them
     // directly (the one-launch forms speculate on few duplicates: hopeless here)
-    const bool rec8 = !slack && !rec12 && dup_heavy && mode == INS_PLUS && vbase == nullptr && PB <= 18 && !getenv("KH_DISABLE_REC8");
+    const bool rec8 = !slack && !rec12 && dup_heavy && mode == INS_PLUS && vbase == nullptr && !getenv("KH_DISABLE_REC8");
     const int kind = rec12 ? 1 : rec8 ? 2 : 0;
     ulonglong2 *tmp, *fin, *spare;
     { char *a, *b; const size_t rb = kind == 1 ? sizeof(KhRec12) : kind == 2 ? sizeof(KhRec8) : sizeof(ulonglong2);
@@ -1354,7 +1355,7 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
   // fold) -- no probe at random into HBM.  Speculative like the other one-launch forms: a chunk whose elements + erase keys exceed the
   // staging area, a carry chain or a poll time-out send the batch down the mark + re-layout path below.
   const uint32_t PBe = t->cur.cap > KH_L ? log2u(t->cur.cap >> KH_LB) : 0u;
-  if (t->kind == KHK_RH && !g_disable_fused_rebuild && !getenv("KH_DISABLE_STREAM_ERASE") && t->cur.cap >= 2 * (uint64_t)KH_L && PBe <= 18 &&
+  if (t->kind == KHK_RH && !g_disable_fused_rebuild && !getenv("KH_DISABLE_STREAM_ERASE") && t->cur.cap >= 2 * (uint64_t)KH_L && PBe <= 22 &&
       t->lsize > 0 && t->lsize <= threshold(t->cur.cap, 0.9f) && n <= 0xFFFFFFF0ull) {
     const size_t keep_blk = t->blk, keep_off = t->off;
     // hashed erase keys fill the chunks evenly: histogram-free partition into fixed slots (two passes for more than 2^11 chunks); a
