@@ -609,7 +609,12 @@ def run_rank(args):
 
     extras = None
     if not distributed and not args.no_extras and args.workload == "w2":
-        extras = run_extras(args, dev, keys, vals, q, dk, dv, dq)
+        try:            # informational legs: a failure here must not take the headline measurement (already complete) with it
+            extras = run_extras(args, dev, keys, vals, q, dk, dv, dq)
+        except Exception as e:
+            import traceback
+            traceback.print_exc()
+            extras = {"extras_error": repr(e)[:500]}
     if rank == 0:
         ops_per_step = (args.keys + args.queries) * world
         ms_per_step = elapsed / args.steps * 1e3
