@@ -502,7 +502,9 @@ class ShardedTable:
         if self.query_pieces > 0:
             return min(int(self.query_pieces), MAX_QUERY_PIECES)
         n = keys.numel()
-        return 4 if n >= (1 << 23) else (2 if n >= (1 << 22) else 1)      # (every piece costs ~0.05 ms of launches: kmerhash_amd_dist.cpp)
+        # measured over RCCL, one rank, self-exchange, 10^7 finds (scripts/dist_query_timing.py): 1.08 / 1.33 / 1.75 ms for 1 / 2 / 4 pieces --
+        # ~0.22 ms of host work per extra piece in this layer (the C++ layer: 0.045 ms), more than the exchange of 10^7 keys can hide
+        return 4 if n >= (1 << 27) else (2 if n >= (1 << 25) else 1)
 
     def _query(self, keys, op):
         """keys out (grouped by owner, in pieces), the local query of a piece while the next one travels, results back with the
@@ -610,6 +612,7 @@ class ShardedTable:
                         self._exchange([(pk, sdn[i], scn[i], rkeys, ro, rcn[i])])
 
             n_erased = 0
+            direct = cuda and hasattr(self.b, "shard_plan")        # the GPU table writes into slices of the result buffers
             keys_out(0)
             status_in = None
             for i in range(rounds):
@@ -630,11 +633,17 @@ class ShardedTable:
                     try:
                         with self._span("local_query"):
                             if op == "count":
-                                lf[a:b] = self.local.count(rkeys[a:b])
+                                if direct:
+                                    self.local.count(rkeys[a:b], out=lf[a:b])
+                                else:
+                                    lf[a:b] = self.local.count(rkeys[a:b])
                             elif op == "find":
-                                v, f = self.local.find_values(rkeys[a:b])
-                                lv[a:b] = v
-                                lf[a:b] = f
+                                if direct:      # straight into the result buffers: nothing allocated or copied, no wait for the device
+                                    self.local.find_values(rkeys[a:b], out_vals=lv[a:b], out_found=lf[a:b], want_total=False)
+                                else:
+                                    v, f = self.local.find_values(rkeys[a:b])
+                                    lv[a:b] = v
+                                    lf[a:b] = f
                             else:
                                 n_erased = self.local.erase(rkeys[a:b])
                     except Exception as e:
@@ -648,7 +657,7 @@ class ShardedTable:
                     arrays.append((lv, so, rcn[i], out_v, sdn[i], scn[i]))
                 arrays.append((lf, so, rcn[i], out_f, sdn[i], scn[i]))
                 if last:        # the status word of this rank's local work rides with the last result exchange
-                    st_out = torch.tensor([self._status_of(ex) if ex is not None else 0], dtype=torch.int64, device=self._ctl_device()).to(rkeys.device)
+                    st_out = torch.full((1,), self._status_of(ex) if ex is not None else 0, dtype=torch.int64, device=rkeys.device)
                     status_in = torch.zeros(p, dtype=torch.int64, device=rkeys.device)
                     arrays.append((st_out, [0] * p, [1] * p, status_in, list(range(p)), [1] * p))
                 if cuda:

@@ -241,28 +241,36 @@ class _HashMapBase:
         self._chk(self._L.kh_insert_reduce_plus(self._h, kb.ptr, vb.ptr if vb is not None else None, kb.n, kb.where, C.byref(out)))
         return out.value
 
-    def count(self, keys):
-        """count(Iter,Iter): 0/1 per query, query order (uint8)."""
+    def count(self, keys, out=None):
+        """count(Iter,Iter): 0/1 per query, query order (uint8).  out: a contiguous uint8 CUDA tensor of the queries' length to write
+        into (device queries only; nothing is allocated or copied then)."""
         kb = _Buf(keys, np.uint64, 8)
         self._sync_stream(kb)
-        out, optr = self._out(kb, kb.n, np.uint8, torch.uint8 if torch else None)
+        if out is not None and kb.where == K.KH_MEM_DEVICE:
+            assert out.is_contiguous() and out.numel() == kb.n and out.element_size() == 1
+            optr = out.data_ptr()
+        else:
+            out, optr = self._out(kb, kb.n, np.uint8, torch.uint8 if torch else None)
         self._chk(self._L.kh_count(self._h, kb.ptr, kb.n, kb.where, optr))
         return out
 
-    def find_values(self, keys):
-        """per-query form: (values, found) aligned with the queries (values of misses are 0)."""
+    def find_values(self, keys, out_vals=None, out_found=None, want_total=True):
+        """per-query form: (values, found) aligned with the queries (values of misses are 0).  out_vals / out_found: contiguous
+        int32 / uint8 CUDA tensors of the queries' length to write into (device queries only; out_vals must hold 0 where a miss is to
+        read 0: the library leaves the values of misses untouched).  want_total=False: the call does not wait for the device."""
         kb = _Buf(keys, np.uint64, 8)
         self._sync_stream(kb)
         if kb.where == K.KH_MEM_DEVICE:
-            vals = torch.zeros(kb.n, dtype=torch.int32, device=kb.device)
-            found = torch.empty(kb.n, dtype=torch.uint8, device=kb.device)
+            vals = out_vals if out_vals is not None else torch.zeros(kb.n, dtype=torch.int32, device=kb.device)
+            found = out_found if out_found is not None else torch.empty(kb.n, dtype=torch.uint8, device=kb.device)
+            assert vals.is_contiguous() and found.is_contiguous() and vals.numel() == kb.n and found.numel() == kb.n
             vptr, fptr = vals.data_ptr(), found.data_ptr()
         else:
             vals = np.zeros(kb.n, dtype=np.uint32)
             found = np.zeros(kb.n, dtype=np.uint8)
             vptr, fptr = vals.ctypes.data, found.ctypes.data
         nf = C.c_uint64()
-        self._chk(self._L.kh_find(self._h, kb.ptr, kb.n, kb.where, vptr, fptr, C.byref(nf)))
+        self._chk(self._L.kh_find(self._h, kb.ptr, kb.n, kb.where, vptr, fptr, C.byref(nf) if want_total else None))
         return vals, found
 
     def find(self, keys):
