@@ -18,6 +18,25 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 KINDS = [(kh.hashmap_robinhood_doubling, 0), (kh.hashmap_linearprobe_doubling, 1)]
 HASHES = [("murmur3avx64", 1), ("murmur", 2), ("farm", 3)]
 t_end = time.time() + budget
+
+
+def oracle_plus(o, ks, vs, mx):
+    """Reducer = std::plus on the oracle (which has no reducer): membership, size and capacity through ONE insert of the batch (the
+    capacity rule of kh_insert_reduce_plus is the batch insert's), then every key of the batch gets old value + its sum -- written with
+    update_one under a max load factor of 4.0, so that the update's own insert() call cannot double the table (an LP table can be
+    100 % full after its shrink quirk: 1.0 would not do)"""
+    uk, inv = np.unique(ks, return_inverse=True)
+    add = np.zeros(len(uk), dtype=np.uint64)
+    np.add.at(add, inv, vs.astype(np.uint64) if vs is not None else np.uint64(1))
+    old, found = o.find(uk)
+    got = o.insert(ks, np.zeros(len(ks), dtype=np.uint32))
+    o.set_max_load_factor(4.0)
+    for k, a, ov, f in zip(uk.tolist(), add.tolist(), old.tolist(), found.tolist()):
+        o.update_one(k, ((ov if f else 0) + a) & 0xFFFFFFFF)
+    o.set_max_load_factor(mx)
+    return got
+
+
 runs = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
@@ -34,7 +53,7 @@ while time.time() < t_end:
     step = -1; op = -1
     try:
         for step in range(40 if not big else 14):
-            op = int(rng.integers(0, 13))
+            op = int(rng.integers(0, 16))
             m = int(rng.choice([0, 1, 3, 50, 2000, 20_000, 150_000])) if not big else int(rng.choice([0, 5, 2000, 300_000, 1_500_000, 4_000_000]))
             if big and kind == 1 and op == 6:
                 m = min(m, 300_000)      # a million tombstones make the REFERENCE's (hence the oracle's) later LP inserts quadratic (seed 950038: minutes per step)
@@ -81,6 +100,34 @@ while time.time() < t_end:
                 assert got == o.insert(ks, vs)
             elif op == 11 and rng.random() < 0.3:
                 g.clear(); o.clear()
+            elif op == 13 and m <= 300_000:                                       # Reducer = std::plus, one call, with or without values
+                use_v = bool(rng.integers(0, 2))
+                assert g.insert_reduce_plus(dev(ks), dev(vs) if use_v else None) == oracle_plus(o, ks, vs if use_v else None, mx)
+            elif op == 14 and 0 < m <= 300_000:                                   # the same streamed (repeatable or not), or aborted half-way
+                cuts = sorted(set([0, m] + [int(x) for x in rng.integers(0, m + 1, int(rng.integers(0, 4)))]))
+                rep = bool(rng.integers(0, 2)); abort = rng.random() < 0.25
+                try:
+                    g.insert_begin(m, reduce_plus=True, repeatable=rep)
+                    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                        if abort and i == len(cuts) - 2:
+                            break
+                        g.insert_feed(dev(ks[a:b]))
+                    got = None
+                    if abort:
+                        g.insert_abort()
+                    else:
+                        got = g.insert_end()
+                except kh.KhRetry:
+                    assert rep and not abort
+                    g.insert_begin(m, reduce_plus=True)
+                    for a, b in zip(cuts[:-1], cuts[1:]):
+                        g.insert_feed(dev(ks[a:b]))
+                    got = g.insert_end()
+                if not abort:
+                    assert got == oracle_plus(o, ks, None, mx)
+            elif op == 15 and m:                                                  # erase of a batch with misses and repeats (streaming form / in place / small)
+                e = np.concatenate([ks, universe[:50] ^ np.uint64(1 << 62), ks[: m // 3]])
+                assert g.erase(dev(e)) == o.erase(e)
             elif op == 12:
                 f = float(rng.choice([0.5, 0.7, 0.8, 0.9]))
                 if f > mn: g.set_max_load_factor(f); o.set_max_load_factor(f); mx = f
