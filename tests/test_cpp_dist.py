@@ -85,3 +85,57 @@ def test_dist_driver_on_gpu(tmp_path):
     assert r.returncode == 0 and "SELF-CHECK FAILED" not in r.stdout + r.stderr, r.stdout + r.stderr
     m = re.search(r"global size after insert (\d+)", r.stdout)
     assert m and 190_000 < int(m.group(1)) <= 200_000, r.stdout        # 10^6 draws from the file's 200000 keys
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_dist_library_in_process_one_rcc_rank_forced_collectives():
+    """libkmerhash_amd_dist.so loaded INTO this process (ctypes): one RCCL rank with KHD_OPT_FORCE_COLLECTIVES runs the count exchange, the
+    grouped all-to-all-v of every piece, the votes and the pipelined find as self-exchanges; results equal the plain table's"""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import kmerhash_amd as kh
+    from kmerhash_amd import workloads as W
+    lib = _build()
+    L = C.CDLL(lib)
+    vp, u64 = C.c_void_p, C.c_uint64
+    L.khd_unique_id.argtypes = [vp]
+    L.khd_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64, u64, C.c_float, C.c_float, C.c_int, u64]
+    L.khd_set_option.argtypes = [vp, C.c_int, C.c_longlong]
+    L.khd_insert.argtypes = [vp, vp, vp, u64, C.c_int, C.c_int, C.POINTER(u64)]
+    L.khd_find.argtypes = [vp, vp, u64, vp, vp, vp]
+    L.khd_erase.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.khd_size.argtypes = [vp, C.POINTER(u64)]
+    L.khd_synchronize.argtypes = [vp]
+    L.khd_destroy.argtypes = [vp]
+    L.khd_last_error.argtypes = [vp]
+    L.khd_last_error.restype = C.c_char_p
+    ident = C.create_string_buffer(128)
+    assert L.khd_unique_id(ident) == 0
+    m = vp()
+    assert L.khd_create(C.byref(m), ident, 1, 0, 0, 0, 1, 43, 128, 0.35, 0.8, 1, 9876543) == 0
+    assert L.khd_set_option(m, 1, 1) == 0 and L.khd_set_option(m, 2, 2) == 0          # force collectives; 2 query pieces
+    n = 600_000
+    keys = W.distinct_u64(n, seed=61)
+    keys[-2000:] = keys[:2000]
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    dv = torch.arange(n, dtype=torch.int32, device="cuda")
+    ni = u64()
+    assert L.khd_insert(m, dk.data_ptr(), dv.data_ptr(), n, 3, 0, C.byref(ni)) == 0, L.khd_last_error(m)
+    plain = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    assert plain.insert(dk, dv) == ni.value == n - 2000
+    gs = u64()
+    assert L.khd_size(m, C.byref(gs)) == 0 and gs.value == n - 2000
+    q = torch.cat([dk[:50_000], torch.from_numpy(W.distinct_u64(20_000, seed=62).view(np.int64)).cuda()])
+    ok = torch.empty_like(q)
+    ov = torch.empty(q.numel(), dtype=torch.int32, device="cuda")
+    of = torch.empty(q.numel(), dtype=torch.uint8, device="cuda")
+    assert L.khd_find(m, q.data_ptr(), q.numel(), ok.data_ptr(), ov.data_ptr(), of.data_ptr()) == 0
+    assert L.khd_synchronize(m) == 0
+    pv, pf = plain.find_values(q)
+    assert torch.equal(ok, q) and torch.equal(of, pf) and torch.equal(ov[of == 1], pv[pf == 1])
+    ne = u64()
+    assert L.khd_erase(m, q.data_ptr(), q.numel(), C.byref(ne)) == 0 and ne.value == plain.erase(q)
+    assert L.khd_destroy(m) == 0
+    plain.close()
