@@ -2290,6 +2290,256 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
   KH_STAMP(8);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The bulk build of a duplicate-free batch, lean: k_build_fused<KIND, HASH, 0> with nodup = 1 over ONE source of 12-byte records, i.e.
+// the benchmark case (distinct keys into an empty table), as its own kernel so that its LDS can be cut to what that case needs:
+// values as 32-bit words (no stream positions travel with 12-byte records), home counts / fill counters as packed 16-bit fields
+// and slot starts as 16-bit words (a chunk holds < 2048 records), no de-dup set.  36.7 KB instead of 53.6 KB: FOUR workgroups per CU
+// instead of three (the kernel is bound by latency and instruction issue, 77 % of the issue slots at three).  Same protocol as
+// k_build_fused (published granules, one-deep look-back, flags, early give-up vote, chunk 0 parked for the tail launch); any
+// duplicate -- found by the same group check after the placement, or by an all-pairs check in chunk 0, which is not placed here --
+// raises KH_FLAG_FUSE_INVALID and the host repeats the batch with 16-byte records.
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int HASH>
+__global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParams P) {      // (8 waves per SIMD = 4 workgroups per CU: <= 64 VGPRs, <= 96 SGPRs)
+  __shared__ unsigned long long lk[KH_DD_M];
+  __shared__ uint32_t lv[KH_DD_M];
+  __shared__ uint32_t cnt16[KH_L / 2];           // two 16-bit counters per word: home counts, then fill counters (= group sizes at the end)
+  __shared__ uint16_t start[KH_L];
+  __shared__ __align__(8) uint16_t simg[KH_L + KH_FSPILL];
+  __shared__ KhMP32 s_wtot[KH_CHUNK_THREADS / 64];
+  __shared__ uint32_t s_x, s_abort, s_dup;
+  __shared__ long long s_pend;
+  const uint32_t tid = threadIdx.x;
+  const uint64_t cap = P.New.cap, mask_n = cap - 1;
+  const uint32_t nch = (uint32_t)(cap >> KH_LB);
+  const uint32_t c = blockIdx.x;
+  const uint64_t Sc = (uint64_t)c * KH_L;
+  const unsigned long long VALID = 1ull << 63;
+  if (tid == 0) { s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dup = 0; }
+  // (one histogram-free or exact source of 12-byte records: addressed directly, no source table)
+  const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
+  const KhRec12* src; uint32_t m;
+  if (P.src.slot[0]) {
+    const uint64_t b = (uint64_t)q * P.src.slot[0], e = P.src.cur[0][q] - b;
+    src = reinterpret_cast<const KhRec12*>(P.src.rec[0]) + b;
+    m = (uint32_t)(e < P.src.slot[0] ? e : P.src.slot[0]);
+  } else {
+    const uint64_t b = P.src.off[0][q];
+    src = reinterpret_cast<const KhRec12*>(P.src.rec[0]) + b;
+    m = (uint32_t)(P.src.off[0][q + 1] - b);
+  }
+  __syncthreads();
+  const bool aborted = s_abort != 0;
+  if (m >= KH_DD_M || aborted) {
+    if (tid == 0) {
+      if (!aborted) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+      __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (m) {     // all (<= 4) records of a lane are requested before the first one is stored (clamped indices, no branch per record)
+    KhRec12 r3[KH_DD_M / KH_CHUNK_THREADS];
+    const uint32_t last = m - 1u;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; r3[it] = src[i < last ? i : last]; }
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      const uint32_t i = it * KH_CHUNK_THREADS + tid;
+      if (i < m) { lk[i] = r3[it].klo | ((uint64_t)r3[it].khi << 32); lv[i] = r3[it].val; }
+    }
+  }
+  for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
+  for (uint32_t i = tid; i < KH_L / 2; i += KH_CHUNK_THREADS) cnt16[i] = 0;
+  __syncthreads();
+  // ---- home counts
+  uint32_t hb[KH_DD_M / KH_CHUNK_THREADS];
+#pragma unroll
+  for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+    hb[it] = 0;
+    const uint32_t x = it * KH_CHUNK_THREADS + tid;
+    if (x < m) {
+      hb[it] = (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc);
+      atomicAdd(&cnt16[hb[it] >> 1], 1u << (16 * (hb[it] & 1)));
+    }
+  }
+  __syncthreads();
+  uint32_t cb[KH_HOMES_PER_THREAD];
+  KhMP32 v; v.A = KH_MP32_NEG; v.n = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+    const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+    cb[j] = (cnt16[b >> 1] >> (16 * (b & 1))) & 0xFFFFu;
+    KhMP32 h; h.A = (int)(b + cb[j]); h.n = (int)cb[j];
+    v = kh_mp_combine(v, h);
+  }
+  KhMP32 total;
+  const KhMP32 excl = kh_block_scan_mp32(v, s_wtot, &total);
+  const uint32_t n_c = (uint32_t)total.n;      // == m: every record stands for itself
+  const long long spill0 = total.A > (long long)KH_L ? total.A - (long long)KH_L : 0;
+  const bool early = n_c + KH_XB <= KH_L;
+  if (c == 0) {     // circular table: chunk 0 follows the last chunk -> publish, park, and leave the placement to the tail launch
+    // (not placed here, so the group check below never sees it: every record is compared with the records behind it instead --
+    //  one workgroup, once per build)
+    bool dup = false;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      const uint32_t x = it * KH_CHUNK_THREADS + tid;
+      if (x < m) {
+        const unsigned long long key = lk[x];
+        for (uint32_t y = x + 1; y < m; ++y) dup = dup || kh_keq(lk[y], key, P.seed.xk);
+      }
+    }
+    if (__any(dup) && (tid & 63) == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+    if (tid == 0) {
+      if (!early) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+      __hip_atomic_store(&P.pub[0], VALID | ((unsigned long long)spill0 << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      P.maxidx[0] = 0;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) P.homecnt0[tid * KH_HOMES_PER_THREAD + j] = (uint16_t)cb[j];
+    for (uint32_t x = tid; x < m; x += KH_CHUNK_THREADS) { P.ck0[x] = lk[x]; P.cv0[x] = lv[x]; }
+    return;
+  }
+  // ---- publish / look back (as k_build_fused)
+  if (tid == 0) {
+    if (c < 64) {     // the first 64 chunks vote on the duplicate ratio (all records distinct here: the vote can only confirm)
+      const unsigned long long mine = ((unsigned long long)n_c << 32) | m;
+      const unsigned long long tot = atomicAdd(&P.est[0], mine) + mine;
+      const uint32_t sn = (uint32_t)(tot >> 32), sm = (uint32_t)tot;
+      if ((c == 63 || (nch < 64 && c == nch - 1)) && sm > 0) {
+        const double dhat = (double)P.base_size + (double)P.n_total * (double)sn / (double)sm * 1.15;
+        if (dhat <= (double)P.half_max_load) {
+          atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+          __hip_atomic_store(&P.est[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (early) __hip_atomic_store(&P.pub[c], VALID | ((unsigned long long)spill0 << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t pc = c - 1;
+    unsigned long long w = 0;
+    const long long t0 = clock64();
+    for (;;) {
+      w = __hip_atomic_load(&P.pub[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w & VALID) break;
+      if (clock64() - t0 > P.poll_limit) { atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u); w = VALID; break; }   // bounded: then the general path
+      __builtin_amdgcn_s_sleep(4);
+    }
+    const uint32_t x = (uint32_t)((w >> 32) & 0x7FFFFFFFu);
+    if (x > KH_XB) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);       // a carry chain: general path
+    if (!early) {
+      const long long e = (long long)x + n_c;
+      const long long pe = total.A > e ? total.A : e;
+      const long long sp = pe > (long long)KH_L ? pe - (long long)KH_L : 0;
+      __hip_atomic_store(&P.pub[c], VALID | ((unsigned long long)sp << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_x = x;
+    P.maxidx[c] = 0;
+  }
+  __syncthreads();
+  // ---- placement with the carry-in
+  const long long xr = (long long)s_x;
+  long long p = excl.A > xr + excl.n ? excl.A : xr + excl.n;
+#pragma unroll
+  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+    const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+    const long long st = p > (long long)b ? p : (long long)b;
+    start[b] = (uint16_t)st;                 // (< KH_L + KH_XB + 2048: fits 16 bits)
+    p = st + cb[j];
+  }
+  if (tid == KH_CHUNK_THREADS - 1) s_pend = p;
+  // (the fill counters: every thread owns the two words of its four homes)
+  cnt16[tid * (KH_HOMES_PER_THREAD / 2)] = 0; cnt16[tid * (KH_HOMES_PER_THREAD / 2) + 1] = 0;
+  static_assert(KH_HOMES_PER_THREAD == 4, "two packed counter words per thread");
+  __syncthreads();
+  uint32_t pr[KH_DD_M / KH_CHUNK_THREADS];       // slot (relative to the chunk) every record of this lane went to
+#pragma unroll
+  for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+    pr[it] = 0;
+    const uint32_t x = it * KH_CHUNK_THREADS + tid;
+    if (x < m) {
+      const uint32_t b = hb[it];
+      const uint32_t r = (atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1))) >> (16 * (b & 1))) & 0xFFFFu;
+      const uint32_t prel = start[b] + r;
+      pr[it] = prel;
+      uint32_t dist = prel - b;
+      if (KIND == KHK_RH && dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
+      if (prel < KH_L + KH_FSPILL) simg[prel] = (uint16_t)(x | ((dist < 31u ? dist : 31u) << 11));   // record index | distance code
+      else kh_slot_st(P.New.s + ((Sc + prel) & mask_n), lk[x], lv[x], KIND == KHK_RH ? (0x80u | dist) : 0x00u);
+    }
+  }
+  __syncthreads();
+  {
+    // equal keys share their home bucket, hence sit in one group of consecutive slots [start[b], start[b] + size[b]): every element
+    // compares itself with the elements of its group BEHIND it (as k_build_fused's nodup check)
+    bool dup = false;
+    uint32_t gend[KH_DD_M / KH_CHUNK_THREADS];
+    unsigned long long mykey[KH_DD_M / KH_CHUNK_THREADS];
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      gend[it] = 0;
+      const uint32_t x = it * KH_CHUNK_THREADS + tid;
+      if (x < m) {
+        const uint32_t b = hb[it];
+        gend[it] = start[b] + ((cnt16[b >> 1] >> (16 * (b & 1))) & 0xFFFFu);
+        if (gend[it] > KH_L + KH_FSPILL) { dup = true; gend[it] = 0; }       // part of the group went past the image: cannot be checked here
+      }
+      ++pr[it];
+      mykey[it] = lk[x < KH_DD_M ? x : 0];
+    }
+    constexpr uint32_t KH_DUPK = 3;
+    uint32_t ei[KH_DD_M / KH_CHUNK_THREADS][KH_DUPK];
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it)
+#pragma unroll
+      for (uint32_t d = 0; d < KH_DUPK; ++d) ei[it][d] = simg[pr[it] + d < gend[it] ? pr[it] + d : 0u] & 0x7FFu;
+    bool more = false;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+#pragma unroll
+      for (uint32_t d = 0; d < KH_DUPK; ++d)
+        if (kh_keq(lk[ei[it][d]], mykey[it], P.seed.xk) && pr[it] + d < gend[it]) dup = true;
+      pr[it] += KH_DUPK;
+      more = more || pr[it] < gend[it];
+    }
+    while (__any(more)) {
+      more = false;
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+        if (pr[it] < gend[it]) {
+          if (kh_keq(lk[simg[pr[it]] & 0x7FFu], mykey[it], P.seed.xk)) dup = true;
+          ++pr[it];
+          more = more || pr[it] < gend[it];
+        }
+      }
+    }
+    if (__any(dup) && (tid & 63) == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+  }
+  long long pend = s_pend;
+  if (pend < (long long)KH_L) pend = KH_L;
+  const uint32_t lo = (uint32_t)xr;
+  const uint32_t hi = pend < (long long)(KH_L + KH_FSPILL) ? (uint32_t)pend : (KH_L + KH_FSPILL);
+  for (uint32_t s0 = lo + tid; s0 < hi; s0 += KH_CHUNK_THREADS) {
+    KhSlot* dst = P.New.s + ((Sc + s0) & mask_n);
+    const uint32_t e = simg[s0];
+    if (e == 0xFFFFu) kh_slot_st(dst, 0, 0, kh_empty_info<KIND>());
+    else {
+      const uint32_t x = e & 0x7FFu;
+      const uint64_t key = lk[x];
+      uint32_t ib = 0x00u;
+      if (KIND == KHK_RH) {
+        uint32_t dist = e >> 11;
+        if (dist == 31u) {
+          dist = s0 - (uint32_t)((kh_hash64<HASH>(key, P.seed) & mask_n) - Sc);
+          if (dist > 127u) dist = 127u;
+        }
+        ib = 0x80u | dist;
+      }
+      kh_slot_st(dst, key, lv[x], ib);
+    }
+  }
+}
+
 // carry-in of chunk 0 = run-over of the last chunk (circular table)
 // (also what the tail placement of chunk 0 needs besides: its list offsets {0, 0} and its list length = the count field of pub[0] --
 //  one launch instead of a kernel, a fill and a copy)

@@ -335,6 +335,7 @@ const bool g_disable_fused_rebuild = getenv("KH_DISABLE_FUSED_BUILD") != nullptr
 // [0] elements placed, [1] max(first-occurrence position + 1), bytes 32..: the vote words, bytes 64..: the flags.
 const long long g_poll_limit = getenv("KH_DEBUG_POLL_LIMIT") ? atoll(getenv("KH_DEBUG_POLL_LIMIT")) : (1ll << 23);     // test hook: look-back time-out
 struct FusedRun { unsigned long long* totals; uint32_t* flags; };
+const bool g_disable_lean = getenv("KH_DISABLE_LEAN_BUILD") != nullptr;      // test hook / A-B: the general one-launch build for 12-byte records too
 kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw, uint32_t PB_tail, const char* name, FusedRun* out) {
   const uint32_t nch = (uint32_t)(nw.cap >> KH_LB);
   char* blk; uint32_t* maxidx; uint64_t* ck0; uint32_t* cv0; uint16_t* hc0; long long* xc0; uint64_t* noff0; uint32_t* ncnt0;
@@ -353,7 +354,9 @@ kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw
   F.poll_limit = g_poll_limit;
   F.R.New = nw; F.R.seed = t->seed; F.R.flags = F.flags;
   { Launch L(t, name);
-    if (src == 0) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 0>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    // (the benchmark case -- a duplicate-free sample, one source of 12-byte records -- has its own kernel with 17 KB less LDS: 4 workgroups per CU)
+    if (src == 0 && F.nodup && F.src.rec12 == 1 && F.src.n == 1 && !g_disable_lean) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_lean<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    else if (src == 0) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 0>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 1) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 3) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 3>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }      // (batch erase: Robin Hood only)
     else { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); } }

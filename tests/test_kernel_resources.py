@@ -27,11 +27,16 @@ def test_no_scratch_no_spills(resources):
         # workgroup since the deferred reducer-plus list joined it), never on the kernels the configs[1] benchmark runs
         if "k_dedup" in name:
             assert r.get("SGPRSpill", 0) <= 12, (name, r)
+        elif "k_build_lean" in name:
+            # the lean bulk build is compiled for 8 waves per SIMD (4 workgroups per CU): the 800 scalar registers of a SIMD then leave 96
+            # per wave and ~30 of its ~105 scalars live in vector lanes instead (v_writelane / v_readlane, no memory): measured 6 % faster
+            # insert than 3 workgroups per CU without spills
+            assert r.get("SGPRSpill", 0) <= 40 and r["Occupancy"] >= 8 and r["LDS"] <= 40960, (name, r)
         elif "k_ip_serial" not in name and "k_small_batch" not in name and not ("k_find" in name and "Lb1E" in name):
             assert r.get("SGPRSpill", 0) == 0, (name, r)
 
 
-@pytest.mark.parametrize("kernel,min_occ", [("k_build_fused", 6), ("k_dedup", 6), ("k_chunk_place", 6), ("k_part_scatter", 4)])
+@pytest.mark.parametrize("kernel,min_occ", [("k_build_fused", 6), ("k_build_lean", 8), ("k_dedup", 6), ("k_chunk_place", 6), ("k_part_scatter", 4)])
 def test_lds_bound_kernels_keep_their_occupancy(resources, kernel, min_occ):
     hits = {n: r for n, r in resources.items() if kernel + "I" in n}
     assert hits, kernel
