@@ -11,7 +11,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-STREAMING = ("k_part_scatter", "k_part_hist", "k_build_fused", "k_dedup", "k_chunk_place", "k_chunk_count", "k_gather_new", "k_compact_hits",
+STREAMING = ("k_part_scatter", "k_part_hist", "k_build_fused", "k_build_lean", "k_dedup", "k_chunk_place", "k_chunk_count", "k_gather_new", "k_compact_hits",
              "k_shard", "k_flag_tile_sums", "k_occupied_flags")
 ks = glob.glob("gpurun_out/prof_%s/*/*_kernel_stats.csv" % tag)
 if ks:
@@ -43,7 +43,7 @@ for k, e in res.items():
     e["hbm_bytes_per_launch"] = e["read_bytes_per_launch"] + w
 # HBM bytes of one insert batch = sum over the kernels of the insert path (everything but the query kernels), per bench step
 # (the PMC passes run bench.py --steps 1 --warmup 0: launches = launches per batch)
-INSERT_PATH = ("k_part_", "k_build_fused", "k_fused_", "k_make_tiles", "k_scan", "k_init_cursors", "k_sample_dups", "k_seg_offsets", "k_dedup", "k_chunk_")
+INSERT_PATH = ("k_part_", "k_build_fused", "k_build_lean", "k_fused_", "k_make_tiles", "k_scan", "k_init_cursors", "k_sample_dups", "k_seg_offsets", "k_dedup", "k_chunk_")
 ins = sum(e["hbm_bytes_per_launch"] * max(e.get("FETCH_SIZE_launches", 0), e.get("WRITE_SIZE_launches", 0)) for k, e in res.items() if k.startswith(INSERT_PATH))
 res["_insert_path"] = {"hbm_bytes_per_batch": ins, "kernels": sorted(k for k in res if k.startswith(INSERT_PATH))}
 json.dump(res, open("profiles/%s_pmc_hbm_traffic.json" % tag, "w"), indent=1, sort_keys=True)
