@@ -1366,3 +1366,27 @@ def test_random_sequences_with_reducer_plus_and_aborts(oracle, kname, cls, kind,
         mk = np.array(sorted(model), dtype=np.uint64)
         assert np.array_equal(sk, mk) and np.array_equal(sv, np.array([model[k] for k in mk.tolist()], dtype=np.uint32)), (step, op, m)
     g.close()
+
+
+@pytest.mark.parametrize("hidden", [0, 300])
+def test_lean_bulk_build_with_key_transform(oracle, hidden):
+    """k_build_lean (duplicate-free sample, 12-byte records, 4 workgroups per CU) on a bimolecule table: 4e6 31-mers hashed and compared as
+    min(k-mer, reverse complement).  hidden = 300: that many k-mers occur a second time as their OTHER strand, none at a sampled
+    position -- equal keys under the transform, which the group check after the placement must find (retry with 16-byte records, first
+    occurrence's bits stored)."""
+    k, n = 31, 4_000_000
+    top = np.uint64((1 << (2 * k)) - 1)
+    keys = W.distinct_u64(n, seed=91) & top
+    if hidden:
+        pos = (n // 65536) * np.arange(2000, 2000 + hidden) + 5
+        keys[pos] = _revcomp(keys[(n // 65536) * np.arange(9000, 9000 + hidden) + 9], k)
+    vals = np.arange(n, dtype=np.uint32)
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash="farm"); g.set_key_transform(k)
+    o = oracle.OracleTable(0, 128, 0.35, 0.8, 3, 43); o.set_key_transform(k)
+    g.profile_enable(True)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals)
+    p = g.profile()
+    assert p["k_build_fused"][0] == (2 if hidden else 1) and "k_dedup" not in p, p      # (the label covers k_build_lean: one launch, or lean + its retry)
+    check_state(g, o, 0)
+    check_queries(g, o, np.concatenate([keys[:3000], _revcomp(keys[5000:8000], k), W.distinct_u64(2000, seed=92) & top]))
+    g.close()
