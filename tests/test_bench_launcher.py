@@ -62,3 +62,23 @@ def test_two_rank_control_flow_rehearsal_on_one_gpu():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["config"]["exchange_pieces"] == 4
     assert set(d["phases_ms_per_step_rank0"]) >= {"count_pass", "permute", "exchange", "feed", "build"}
+
+
+def test_bench_generators_and_host_cores_on_cpu():
+    """the device-side workload generators of bench.py's informational legs (run here on CPU tensors) keep their shapes: W1 = 62-bit keys
+    with mean multiplicity 5.5 and a permutation as values, W3 = distinct 62-bit keys x mult; the torch splitmix64 equals the numpy one"""
+    import numpy as np
+    import torch
+    import bench
+    from kmerhash_amd import workloads as W
+    x = np.arange(2000, dtype=np.uint64) * np.uint64(0x123456789ABCDEF1)
+    assert np.array_equal(W.splitmix64(x), bench._splitmix64_t(torch.from_numpy(x.view(np.int64))).numpy().view(np.uint64))
+    k, v = bench.gpu_w1(50_000, torch.device("cpu"))
+    assert k.numel() == 50_000 and int(k.min()) >= 0 and int(k.max()) < (1 << 62)
+    assert 4.5 < 50_000 / torch.unique(k).numel() < 6.5 and sorted(v.tolist()) == list(range(50_000))
+    base, k3, v3 = bench.gpu_w3(5_000, torch.device("cpu"))
+    assert torch.unique(base).numel() == 5_000 and k3.numel() == 25_000 and torch.unique(k3).numel() == 5_000 and int(base.max()) < (1 << 62)
+    hc = bench.host_cores()
+    assert hc["logical"] >= 1 and hc["affinity"] >= 1 and (hc["physical"] is None or 1 <= hc["physical"] <= hc["logical"])
+    s = bench._stat([1.0, 3.0, 2.0], 1_000_000, 50)
+    assert s["ms_median"] == 2.0 and s["ms_min"] == 1.0 and abs(s["ops_per_s"] - 5e8) < 1 and abs(s["frac"] - 5e8 * 50 / 8e12) < 1e-12
