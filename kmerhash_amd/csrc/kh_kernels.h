@@ -586,6 +586,11 @@ struct KhPartParams {
   uint64_t dump;                           // first record of the dump area in orec (KH_PART_TILE records)
   uint32_t* overflow;
   int xcd_swizzle;                         // eight consecutive tiles per XCD (adjacent output runs meet in one L2; speed only)
+  // second pass over the fixed slots of a histogram-free first pass, tiles by arithmetic (tiles == null): input segment s is the slot
+  // [s * slot_in, cur_in[s]) of rec_in, cut into tps tiles of KH_PART_TILE records -- tile t = (segment t / tps, piece t % tps).  A
+  // workgroup then knows where its records lie without reading a tile list: it requests them together with the segment's cursor
+  // (ONE HBM round trip before the first record arrives instead of three: tile count, tile, records) and drops what lies behind the fill.
+  uint64_t slot_in; const unsigned long long* cur_in; uint32_t tps;
   // (k_part_scatter<HASH, true>: rec_in / orec hold KhRec12 records instead -- histogram-free mode only)
 };
 
@@ -694,16 +699,26 @@ __global__ KH_PART_LB(RK) void k_part_scatter(KhPartParams P) {
     const uint32_t x = tile & 7u, j = (tile >> 3) & 7u;
     tile = (tile & ~63u) + x * 8u + j;
   }
-  KhTile d = kh_get_tile(P, tile);
-  if (d.len == 0) return;
+  KhTile d;
+  uint32_t last;                                    // index the requests are clamped to
+  unsigned long long fill_end = 0;
+  if (P.slot_in) {                                  // (arithmetic tiles over fixed slots: the tile's length arrives with its records)
+    const uint32_t seg = tile / P.tps, k = tile - seg * P.tps;
+    fill_end = P.cur_in[seg];
+    d.seg = seg; d.beg = (uint64_t)seg * P.slot_in + (uint64_t)k * KH_PART_TILE; d.len = 0;
+    const uint64_t room = P.slot_in - (uint64_t)k * KH_PART_TILE;      // (> 0: tps = ceil(slot_in / KH_PART_TILE) at most)
+    last = (room < KH_PART_TILE ? (uint32_t)room : KH_PART_TILE) - 1u;
+  } else {
+    d = kh_get_tile(P, tile);
+    if (d.len == 0) return;
+    last = d.len - 1u;                              // (a tile holds at least one record)
+  }
   for (uint32_t i = tid; i < nb; i += KH_PART_THREADS) hist[i] = 0;
-  __syncthreads();
   uint64_t key[KH_PART_ITEMS];
   unsigned long long iv[KH_PART_ITEMS];
   uint32_t dr[KH_PART_ITEMS];                   // digit << 16 | rank inside the digit (rank < 8192)
   // every lane requests all its records before it looks at the first one (indices past the tile's end are clamped, not predicated:
   // a branch per item makes the compiler wait for each load in turn -- 16 dependent HBM round trips per tile)
-  const uint32_t last = d.len - 1u;                 // (a tile holds at least one record)
   if (P.rec_in) {
     const Rec* src = reinterpret_cast<const Rec*>(P.rec_in) + d.beg;
     Rec rr[KH_PART_ITEMS];
@@ -735,6 +750,17 @@ __global__ KH_PART_LB(RK) void k_part_scatter(KhPartParams P) {
       for (int j = 0; j < KH_PART_ITEMS; ++j) iv[j] |= (unsigned long long)(pos0 + tid + j * KH_PART_THREADS) << 32;
     }
   }
+  if (P.slot_in) {
+    const uint64_t sbeg = (uint64_t)d.seg * P.slot_in;
+    uint64_t fill = fill_end - sbeg;
+    if (fill > P.slot_in) fill = P.slot_in;                                // (the first pass sent what ran over to its dump area, flagged)
+    const uint64_t off = d.beg - sbeg;
+    // (the host cuts the slot into tiles up to mean + 9 sigma of a segment's fill, not up to the slot's end: a fill beyond that is flagged too)
+    if (off == (uint64_t)(P.tps - 1u) * KH_PART_TILE && fill > (uint64_t)P.tps * KH_PART_TILE && tid == 0) *P.overflow = 1u;
+    d.len = fill > off ? (fill - off < KH_PART_TILE ? (uint32_t)(fill - off) : KH_PART_TILE) : 0u;
+    if (d.len == 0) return;
+  }
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < KH_PART_ITEMS; ++j) {
     const uint32_t i = tid + j * KH_PART_THREADS;
@@ -2018,12 +2044,24 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     // batch's erase keys of this chunk (8-byte records, partitioned by chunk like an insert batch); an element whose key is among
     // them is dropped -- what erase_no_resize's backward shift leaves (hashmap_robinhood.hpp:1294-1356)
     const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
-    const KhSrcView V = kh_src_setup8(P.src, q);
-    for (uint32_t s = tid; s < KH_HS; s += KH_CHUNK_THREADS) set[s] = 0;
+    for (uint32_t s = tid; s < KH_L; s += KH_CHUNK_THREADS) set[s] = 0;      // (list heads per home bucket, below)
     // the erase keys are requested BEFORE the table's slots (clamped indices, no branch per key: all loads of a lane in flight
-    // together), so that the chunk pays one HBM round trip for both, not two in a row
+    // together), so that the chunk pays one HBM round trip for both, not two in a row -- and with a histogram-free partition (a slot
+    // whose place does not depend on its fill) together with the slot's cursor as well: indices clamped to the slot, whatever lies
+    // behind the fill is dropped below
     uint64_t kk[KH_DD_M / KH_CHUNK_THREADS];
-    {
+    KhSrcView V;
+    V.n = 1; V.one = nullptr; V.one12 = nullptr;
+    if (P.src.slot[0]) {
+      const uint64_t b = (uint64_t)q * P.src.slot[0];
+      V.one8 = reinterpret_cast<const uint64_t*>(P.src.rec[0]) + b;
+      const uint32_t last = (uint32_t)P.src.slot[0] - 1u;
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; kk[it] = V.one8[i < last ? i : last]; }
+      const uint64_t e = P.src.cur[0][q] - b;
+      V.m = (uint32_t)(e < P.src.slot[0] ? e : P.src.slot[0]);
+    } else {
+      V = kh_src_setup8(P.src, q);
       const uint32_t last = V.m ? V.m - 1u : 0u;
       const uint64_t* src8 = V.m ? V.one8 : reinterpret_cast<const uint64_t*>(P.R.Old.s);      // (an empty partition: any valid address)
 #pragma unroll
@@ -2045,16 +2083,12 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     }
     for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
     __syncthreads();
-    // only the ERASE KEYS go into the set (a few per cent of the chunk's records: one CAS each; a key given twice meets itself);
-    // the table's elements then look themselves up read-only -- nearly every first probe meets an empty entry
+    // an erase key can only meet elements of its own home bucket: the erase keys (a few per cent of the chunk's records) are chained per
+    // home bucket -- set[b] = head of bucket b's list (index + 1, 0 = none), the link in the key's unused liv[] entry -- and every element
+    // of the table looks at the head of ITS bucket (home from the info byte, no hash): nearly always 0
     for (uint32_t i = tid; i < V.m; i += KH_CHUNK_THREADS) {
-      const unsigned long long key = lk[n_old + i];
-      uint32_t slot = (uint32_t)kh_fmix64(kh_xf(key, P.seed.xk) + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
-      for (;;) {
-        const uint32_t cur = atomicCAS(&set[slot], 0u, n_old + i + 1u);
-        if (cur == 0 || kh_keq(lk[cur - 1u], key, P.seed.xk)) break;
-        slot = (slot + 1) & (KH_HS - 1);
-      }
+      const uint32_t b = (uint32_t)((kh_hash64<HASH>(lk[n_old + i], P.seed) & mask_n) - Sc) & (KH_L - 1u);
+      liv[n_old + i] = (unsigned long long)atomicExch(&set[b], n_old + i + 1u);
     }
     __syncthreads();
     uint32_t keep = 0;
@@ -2063,13 +2097,11 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       const uint32_t x = it * KH_CHUNK_THREADS + tid;
       if (x < n_old) {
         const unsigned long long key = lk[x];
-        uint32_t slot = (uint32_t)kh_fmix64(kh_xf(key, P.seed.xk) + 0x9E3779B97F4A7C15ull) & (KH_HS - 1);
+        uint32_t e = set[(uint32_t)(liv[x] >> 32) & (KH_L - 1u)];
         bool hit = false;
-        for (;;) {
-          const uint32_t cur = set[slot];
-          if (cur == 0) break;
-          if (kh_keq(lk[cur - 1u], key, P.seed.xk)) { hit = true; break; }
-          slot = (slot + 1) & (KH_HS - 1);
+        while (e) {
+          if (kh_keq(lk[e - 1u], key, P.seed.xk)) { hit = true; break; }
+          e = (uint32_t)liv[e - 1u];
         }
         if (!hit) keep |= 1u << it;
       }
@@ -2319,15 +2351,27 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
   if (tid == 0) { s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dup = 0; }
   // (one histogram-free or exact source of 12-byte records: addressed directly, no source table)
   const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
+  // All (<= 4) records of a lane are requested before the first one is stored (clamped indices, no branch per record).  A histogram-free
+  // partition's records sit in a slot whose place does not depend on its fill: they are requested TOGETHER with the slot's cursor (indices
+  // clamped to the slot, whatever lies behind the fill is dropped below) -- one HBM round trip per chunk, not cursor-then-records.
   const KhRec12* src; uint32_t m;
+  KhRec12 r3[KH_DD_M / KH_CHUNK_THREADS];
   if (P.src.slot[0]) {
-    const uint64_t b = (uint64_t)q * P.src.slot[0], e = P.src.cur[0][q] - b;
+    const uint64_t b = (uint64_t)q * P.src.slot[0];
     src = reinterpret_cast<const KhRec12*>(P.src.rec[0]) + b;
+    const uint32_t last = (uint32_t)P.src.slot[0] - 1u;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; r3[it] = src[i < last ? i : last]; }
+    const uint64_t e = P.src.cur[0][q] - b;
     m = (uint32_t)(e < P.src.slot[0] ? e : P.src.slot[0]);
   } else {
     const uint64_t b = P.src.off[0][q];
     src = reinterpret_cast<const KhRec12*>(P.src.rec[0]) + b;
     m = (uint32_t)(P.src.off[0][q + 1] - b);
+    const uint32_t last = m ? m - 1u : 0u;
+    const KhRec12* from = m ? src : reinterpret_cast<const KhRec12*>(P.src.rec[0]);      // (an empty partition at the end of the buffer: any valid address)
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; r3[it] = from[i < last ? i : last]; }
   }
   __syncthreads();
   const bool aborted = s_abort != 0;
@@ -2338,16 +2382,10 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
     }
     return;
   }
-  if (m) {     // all (<= 4) records of a lane are requested before the first one is stored (clamped indices, no branch per record)
-    KhRec12 r3[KH_DD_M / KH_CHUNK_THREADS];
-    const uint32_t last = m - 1u;
 #pragma unroll
-    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; r3[it] = src[i < last ? i : last]; }
-#pragma unroll
-    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-      const uint32_t i = it * KH_CHUNK_THREADS + tid;
-      if (i < m) { lk[i] = r3[it].klo | ((uint64_t)r3[it].khi << 32); lv[i] = r3[it].val; }
-    }
+  for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+    const uint32_t i = it * KH_CHUNK_THREADS + tid;
+    if (i < m) { lk[i] = r3[it].klo | ((uint64_t)r3[it].khi << 32); lv[i] = r3[it].val; }
   }
   for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
   for (uint32_t i = tid; i < KH_L / 2; i += KH_CHUNK_THREADS) cnt16[i] = 0;

@@ -536,12 +536,17 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     // (a piece of a streamed insert: its level-1 buckets are sized for the piece, the final slots -- shared -- for the whole batch)
     const uint64_t slot = shared ? shared->slot : slack_slot((double)n / (double)nparts);
     const uint64_t slot1 = shared ? slack_slot((double)n / (double)nb1) : slot * nb2;
-    unsigned long long *cur1, *cur2; uint64_t* starts; uint32_t* ovf; KhTile* tiles; uint32_t* ntiles_dev;
-    const uint32_t max_tiles = (uint32_t)(n / KH_PART_TILE) + nb1 + 1;
+    unsigned long long *cur1, *cur2; uint64_t* starts; uint32_t* ovf;
     TAKE(cur1, unsigned long long, nb1);
     if (shared) { cur2 = shared->cur2; starts = shared->starts; ovf = shared->ovf; }
     else { TAKE(cur2, unsigned long long, nparts); TAKE(starts, uint64_t, (size_t)nparts + 1); TAKE(ovf, uint32_t, 1); }
-    TAKE(tiles, KhTile, max_tiles); TAKE(ntiles_dev, uint32_t, 1);
+    // the second pass cuts every level-1 slot into tiles by arithmetic (no tile list, see KhPartParams::slot_in) -- up to mean + 9 sigma of a
+    // level-1 bucket's fill, which is well inside the slot (the union of its partitions' slots: 256 x 7 sigma of THEIR fill); a bucket
+    // that holds more raises the overflow flag like a slot that runs over
+    const double mean1 = (double)n / (double)nb1;
+    const uint64_t fill_cap = std::min<uint64_t>(slot1, (uint64_t)(mean1 + 9.0 * std::sqrt(mean1) + 16.0));
+    const uint32_t tps = (uint32_t)((fill_cap + KH_PART_TILE - 1) / KH_PART_TILE);
+    const uint32_t max_tiles = nb1 * tps;
     if (shared) hipLaunchKernelGGL(k_init_cursors, dim3((nb1 + 255) / 256), dim3(256), 0, t->stream, cur1, (uint64_t*)nullptr, (uint64_t)nb1, slot1);
     else hipLaunchKernelGGL(k_init_cursors2, dim3((nparts + 256) / 256), dim3(256), 0, t->stream, cur1, (uint64_t)nb1, slot1, cur2, starts, (uint64_t)nparts, slot, ovf);
     KhPartParams P;
@@ -555,11 +560,9 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
       if (rec12 == 1) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 1>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
       else if (rec12 == 2) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 2>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); }
       else { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 0>), dim3(P.ntiles), dim3(KH_PART_THREADS), ((nb1 + 1u) & ~1u) * 8 + nb1 * 8, t->stream, P)); } }
-    { Launch L(t, "k_make_tiles");
-      hipLaunchKernelGGL(k_make_tiles, dim3(1), dim3(1024), 0, t->stream, (const uint64_t*)nullptr, nb1, tiles, ntiles_dev, (const unsigned long long*)cur1, slot1); }
     KhPartParams Q = P;
     Q.kbase = nullptr; Q.kstride = 0; Q.vbase = nullptr; Q.vstride = 0; Q.rec_in = tmp;
-    Q.tiles = tiles; Q.ntiles_dev = ntiles_dev; Q.ntiles = max_tiles;
+    Q.tiles = nullptr; Q.ntiles_dev = nullptr; Q.ntiles = max_tiles; Q.slot_in = slot1; Q.cur_in = cur1; Q.tps = tps;
     Q.shift = 0; Q.nb = nb2; Q.cursor = cur2; Q.orec = fin; Q.slot = slot; Q.dump = slot * nparts;
     { Launch L(t, "k_part_scatter");
       if (rec12 == 1) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_part_scatter<HASH, 1>), dim3(max_tiles), dim3(KH_PART_THREADS), ((nb2 + 1u) & ~1u) * 8 + nb2 * 8, t->stream, Q)); }

@@ -18,4 +18,9 @@ for rep in range(4):
     torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
     p = t.profile()
     print("erase %d: wall %.3f ms, kernels %.3f ms  %s" % (ne, wall, sum(v[1] for v in p.values()), {k: round(v[1], 3) for k, v in sorted(p.items(), key=lambda kv: -kv[1][1])}), flush=True)
+    if rep == 0:      # the table afterwards: the erased keys are gone, every other key still carries its value
+        c = t.count(dk)
+        assert int(c[:nq].sum()) == 0 and int(c[nq:].sum()) == n - nq and t.size() == n - nq
+        v, f = t.find_values(dk[nq:])
+        assert bool(f.all()) and bool((v == dv[nq:]).all())
     t.close()
