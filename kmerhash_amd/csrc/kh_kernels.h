@@ -1052,20 +1052,29 @@ __device__ __forceinline__ KhMP32 kh_mp_combine(KhMP32 first, KhMP32 then) {
   r.n = first.n + then.n;
   return r;
 }
+// One step of a wavefront scan through the data-parallel-primitive path of the vector ALU (no LDS crossbar: a __shfl_up is a
+// ds_bpermute_b32, 14 of them in a row made the scan 14 % of the bulk build's chunk time): every lane takes the composite of the lane
+// the DPP control names -- row_shr:1/2/4/8 inside its row of 16, then lane 15 / lane 31 of the rows before it -- or the identity where
+// there is none (old value, bound_ctrl off), and puts it in front of its own.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ KhMP32 kh_mp32_dpp_step(KhMP32 incl) {
+  KhMP32 o;
+  o.A = __builtin_amdgcn_update_dpp(KH_MP32_NEG, incl.A, CTRL, ROW_MASK, 0xF, false);
+  o.n = __builtin_amdgcn_update_dpp(0, incl.n, CTRL, ROW_MASK, 0xF, false);
+  return kh_mp_combine(o, incl);          // (identity in front: unchanged)
+}
 __device__ __forceinline__ KhMP32 kh_block_scan_mp32(KhMP32 v, KhMP32* s_wtot, KhMP32* total) {
   const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
   KhMP32 incl = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    KhMP32 o;
-    o.A = __shfl_up(incl.A, off, 64);
-    o.n = __shfl_up(incl.n, off, 64);
-    if (lane >= (uint32_t)off) incl = kh_mp_combine(o, incl);
-  }
+  incl = kh_mp32_dpp_step<0x111, 0xF>(incl);      // row_shr:1
+  incl = kh_mp32_dpp_step<0x112, 0xF>(incl);      // row_shr:2
+  incl = kh_mp32_dpp_step<0x114, 0xF>(incl);      // row_shr:4
+  incl = kh_mp32_dpp_step<0x118, 0xF>(incl);      // row_shr:8
+  incl = kh_mp32_dpp_step<0x142, 0xA>(incl);      // row_bcast:15 into rows 1 and 3
+  incl = kh_mp32_dpp_step<0x143, 0xC>(incl);      // row_bcast:31 into rows 2 and 3
   KhMP32 excl;
-  excl.A = __shfl_up(incl.A, 1, 64);
-  excl.n = __shfl_up(incl.n, 1, 64);
-  if (lane == 0) { excl.A = KH_MP32_NEG; excl.n = 0; }
+  excl.A = __builtin_amdgcn_update_dpp(KH_MP32_NEG, incl.A, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: the identity)
+  excl.n = __builtin_amdgcn_update_dpp(0, incl.n, 0x138, 0xF, 0xF, false);
   if (lane == 63) s_wtot[wid] = incl;
   __syncthreads();
   KhMP32 wpre; wpre.A = KH_MP32_NEG; wpre.n = 0;
@@ -1079,6 +1088,11 @@ __device__ __forceinline__ KhMP32 kh_block_scan_mp32(KhMP32 v, KhMP32* s_wtot, K
   return kh_mp_combine(wpre, excl);
 }
 
+// fill an LDS array (16-byte aligned, a multiple of 16 bytes) with one 32-bit pattern, one ds_write_b128 per lane and trip
+__device__ __forceinline__ void kh_lds_fill16(void* p, uint32_t bytes, uint32_t word) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  for (uint32_t i = threadIdx.x; i < bytes / 16u; i += blockDim.x) q[i] = make_uint4(word, word, word, word);
+}
 // wave-aggregated append: lanes with `want` get consecutive positions from *counter (one LDS atomic per wave)
 __device__ __forceinline__ uint32_t kh_wave_append(bool want, uint32_t* counter) {
   const unsigned long long m = __ballot(want);
@@ -2332,13 +2346,19 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
 // duplicate -- found by the same group check after the placement, or by an all-pairs check in chunk 0, which is not placed here --
 // raises KH_FLAG_FUSE_INVALID and the host repeats the batch with 16-byte records.
 // ---------------------------------------------------------------------------------------------
+#ifdef KH_TRACE
+#define KH_STAMP_L(i) do { if (threadIdx.x == 0 && blockIdx.x >= 20000 && blockIdx.x < 20512) kh_trace[(blockIdx.x - 20000) * 12 + (i)] = clock64(); } while (0)
+#else
+#define KH_STAMP_L(i)
+#endif
 template <int KIND, int HASH>
 __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParams P) {      // (8 waves per SIMD = 4 workgroups per CU: <= 64 VGPRs, <= 96 SGPRs)
   __shared__ unsigned long long lk[KH_DD_M];
   __shared__ uint32_t lv[KH_DD_M];
-  __shared__ uint32_t cnt16[KH_L / 2];           // two 16-bit counters per word: home counts, then fill counters (= group sizes at the end)
-  __shared__ uint16_t start[KH_L];
-  __shared__ __align__(8) uint16_t simg[KH_L + KH_FSPILL];
+  __shared__ __align__(16) uint32_t cnt16[KH_L / 2];           // two 16-bit counters per word: home counts, then fill counters (= group sizes at the end)
+  __shared__ __align__(8) uint16_t start[KH_L];
+  __shared__ __align__(16) uint16_t simg[KH_L + KH_FSPILL];
+  static_assert(((KH_L + KH_FSPILL) * 2) % 16 == 0 && (KH_L * 2) % 16 == 0, "filled with 16-byte stores");
   __shared__ KhMP32 s_wtot[KH_CHUNK_THREADS / 64];
   __shared__ uint32_t s_x, s_abort, s_dup;
   __shared__ long long s_pend;
@@ -2348,6 +2368,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
   const uint32_t c = blockIdx.x;
   const uint64_t Sc = (uint64_t)c * KH_L;
   const unsigned long long VALID = 1ull << 63;
+  KH_STAMP_L(0);
   if (tid == 0) { s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dup = 0; }
   // (one histogram-free or exact source of 12-byte records: addressed directly, no source table)
   const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
@@ -2356,6 +2377,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
   // clamped to the slot, whatever lies behind the fill is dropped below) -- one HBM round trip per chunk, not cursor-then-records.
   const KhRec12* src; uint32_t m;
   KhRec12 r3[KH_DD_M / KH_CHUNK_THREADS];
+  unsigned long long kreg[KH_DD_M / KH_CHUNK_THREADS];
   if (P.src.slot[0]) {
     const uint64_t b = (uint64_t)q * P.src.slot[0];
     src = reinterpret_cast<const KhRec12*>(P.src.rec[0]) + b;
@@ -2385,11 +2407,14 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
 #pragma unroll
   for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
     const uint32_t i = it * KH_CHUNK_THREADS + tid;
-    if (i < m) { lk[i] = r3[it].klo | ((uint64_t)r3[it].khi << 32); lv[i] = r3[it].val; }
+    kreg[it] = r3[it].klo | ((uint64_t)r3[it].khi << 32);      // (stays in registers for the hash and the duplicate check: two LDS reads less per record)
+    if (i < m) { lk[i] = kreg[it]; lv[i] = r3[it].val; }
   }
-  for (uint32_t i = tid; i < KH_L + KH_FSPILL; i += KH_CHUNK_THREADS) simg[i] = 0xFFFFu;
-  for (uint32_t i = tid; i < KH_L / 2; i += KH_CHUNK_THREADS) cnt16[i] = 0;
+  KH_STAMP_L(1);
+  kh_lds_fill16(simg, sizeof(simg), 0xFFFFFFFFu);
+  kh_lds_fill16(cnt16, sizeof(cnt16), 0u);
   __syncthreads();
+  KH_STAMP_L(2);
   // ---- home counts
   uint32_t hb[KH_DD_M / KH_CHUNK_THREADS];
 #pragma unroll
@@ -2397,11 +2422,12 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
     hb[it] = 0;
     const uint32_t x = it * KH_CHUNK_THREADS + tid;
     if (x < m) {
-      hb[it] = (uint32_t)((kh_hash64<HASH>(lk[x], P.seed) & mask_n) - Sc);
+      hb[it] = (uint32_t)((kh_hash64<HASH>(kreg[it], P.seed) & mask_n) - Sc);
       atomicAdd(&cnt16[hb[it] >> 1], 1u << (16 * (hb[it] & 1)));
     }
   }
   __syncthreads();
+  KH_STAMP_L(3);
   uint32_t cb[KH_HOMES_PER_THREAD];
   KhMP32 v; v.A = KH_MP32_NEG; v.n = 0;
 #pragma unroll
@@ -2416,6 +2442,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
   const uint32_t n_c = (uint32_t)total.n;      // == m: every record stands for itself
   const long long spill0 = total.A > (long long)KH_L ? total.A - (long long)KH_L : 0;
   const bool early = n_c + KH_XB <= KH_L;
+  KH_STAMP_L(4);
   if (c == 0) {     // circular table: chunk 0 follows the last chunk -> publish, park, and leave the placement to the tail launch
     // (not placed here, so the group check below never sees it: every record is compared with the records behind it instead --
     //  one workgroup, once per build)
@@ -2475,16 +2502,19 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
     P.maxidx[c] = 0;
   }
   __syncthreads();
+  KH_STAMP_L(5);
   // ---- placement with the carry-in
   const long long xr = (long long)s_x;
   long long p = excl.A > xr + excl.n ? excl.A : xr + excl.n;
+  uint32_t st4[KH_HOMES_PER_THREAD];
 #pragma unroll
   for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
     const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
     const long long st = p > (long long)b ? p : (long long)b;
-    start[b] = (uint16_t)st;                 // (< KH_L + KH_XB + 2048: fits 16 bits)
+    st4[j] = (uint32_t)st & 0xFFFFu;         // (< KH_L + KH_XB + 2048: fits 16 bits)
     p = st + cb[j];
   }
+  reinterpret_cast<uint2*>(start)[tid] = make_uint2(st4[0] | (st4[1] << 16), st4[2] | (st4[3] << 16));      // (the four starts of a lane: one 8-byte store)
   if (tid == KH_CHUNK_THREADS - 1) s_pend = p;
   // (the fill counters: every thread owns the two words of its four homes)
   cnt16[tid * (KH_HOMES_PER_THREAD / 2)] = 0; cnt16[tid * (KH_HOMES_PER_THREAD / 2) + 1] = 0;
@@ -2507,12 +2537,12 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
     }
   }
   __syncthreads();
+  KH_STAMP_L(6);
   {
     // equal keys share their home bucket, hence sit in one group of consecutive slots [start[b], start[b] + size[b]): every element
     // compares itself with the elements of its group BEHIND it (as k_build_fused's nodup check)
     bool dup = false;
     uint32_t gend[KH_DD_M / KH_CHUNK_THREADS];
-    unsigned long long mykey[KH_DD_M / KH_CHUNK_THREADS];
 #pragma unroll
     for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
       gend[it] = 0;
@@ -2523,7 +2553,6 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
         if (gend[it] > KH_L + KH_FSPILL) { dup = true; gend[it] = 0; }       // part of the group went past the image: cannot be checked here
       }
       ++pr[it];
-      mykey[it] = lk[x < KH_DD_M ? x : 0];
     }
     constexpr uint32_t KH_DUPK = 3;
     uint32_t ei[KH_DD_M / KH_CHUNK_THREADS][KH_DUPK];
@@ -2536,7 +2565,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
     for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
 #pragma unroll
       for (uint32_t d = 0; d < KH_DUPK; ++d)
-        if (kh_keq(lk[ei[it][d]], mykey[it], P.seed.xk) && pr[it] + d < gend[it]) dup = true;
+        if (kh_keq(lk[ei[it][d]], kreg[it], P.seed.xk) && pr[it] + d < gend[it]) dup = true;
       pr[it] += KH_DUPK;
       more = more || pr[it] < gend[it];
     }
@@ -2545,7 +2574,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
 #pragma unroll
       for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
         if (pr[it] < gend[it]) {
-          if (kh_keq(lk[simg[pr[it]] & 0x7FFu], mykey[it], P.seed.xk)) dup = true;
+          if (kh_keq(lk[simg[pr[it]] & 0x7FFu], kreg[it], P.seed.xk)) dup = true;
           ++pr[it];
           more = more || pr[it] < gend[it];
         }
@@ -2553,6 +2582,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
     }
     if (__any(dup) && (tid & 63) == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
   }
+  KH_STAMP_L(7);
   long long pend = s_pend;
   if (pend < (long long)KH_L) pend = KH_L;
   const uint32_t lo = (uint32_t)xr;
@@ -2576,6 +2606,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
       kh_slot_st(dst, key, lv[x], ib);
     }
   }
+  KH_STAMP_L(8);
 }
 
 // carry-in of chunk 0 = run-over of the last chunk (circular table)
