@@ -2351,16 +2351,27 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
 #else
 #define KH_STAMP_L(i)
 #endif
+#define KH_LEAN_M 2016u          // records a chunk of the lean build may hold (its staging arrays: 384 bytes under KH_DD_M's, which is what lets the
+                                 // sorted index below fit next to them in a quarter of a CU's LDS)
 template <int KIND, int HASH>
 __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParams P) {      // (8 waves per SIMD = 4 workgroups per CU: <= 64 VGPRs, <= 96 SGPRs)
-  __shared__ unsigned long long lk[KH_DD_M];
-  __shared__ uint32_t lv[KH_DD_M];
+  __shared__ unsigned long long lk[KH_LEAN_M];
+  __shared__ uint32_t lv[KH_LEAN_M];
   __shared__ __align__(16) uint32_t cnt16[KH_L / 2];           // two 16-bit counters per word: home counts, then fill counters (= group sizes at the end)
-  __shared__ __align__(8) uint16_t start[KH_L];
-  __shared__ __align__(16) uint16_t simg[KH_L + KH_FSPILL];
+  __shared__ __align__(8) uint16_t start0[KH_L];                // first slot of every home bucket's group if nothing ran over from the chunk before
+  // The records are counting-sorted by home bucket WITHOUT the carry-in of the chunk before: sidx[npre[b] + r] = record r of bucket b (npre =
+  // records in the buckets before b).  Everything up to and including the duplicate check works on that order, so the look-back's HBM round
+  // trip (a device-scope load: ~3 K cycles, 14 % of a chunk's time when the workgroup waited for it) is spent under the sort and the check;
+  // only the slot image -- which needs the carry-in: slot = max(start0[b] + r, carry + npre[b] + r) -- is laid out afterwards, over the
+  // then dead sort arrays.
+  __shared__ __align__(16) uint16_t u_sort[KH_L + KH_LEAN_M];   // npre[KH_L] | sidx[KH_LEAN_M]; later simg[KH_L + KH_FSPILL]
+  uint16_t* npre = u_sort;
+  uint16_t* sidx = u_sort + KH_L;
+  uint16_t* simg = u_sort;
+  static_assert(KH_L + KH_LEAN_M >= KH_L + KH_FSPILL, "the slot image fits over the sort arrays");
   static_assert(((KH_L + KH_FSPILL) * 2) % 16 == 0 && (KH_L * 2) % 16 == 0, "filled with 16-byte stores");
   __shared__ KhMP32 s_wtot[KH_CHUNK_THREADS / 64];
-  __shared__ uint32_t s_x, s_abort, s_dup;
+  __shared__ uint32_t s_x, s_abort;
   __shared__ long long s_pend;
   const uint32_t tid = threadIdx.x;
   const uint64_t cap = P.New.cap, mask_n = cap - 1;
@@ -2369,7 +2380,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
   const uint64_t Sc = (uint64_t)c * KH_L;
   const unsigned long long VALID = 1ull << 63;
   KH_STAMP_L(0);
-  if (tid == 0) { s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_dup = 0; }
+  if (tid == 0) s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // (one histogram-free or exact source of 12-byte records: addressed directly, no source table)
   const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
   // All (<= 4) records of a lane are requested before the first one is stored (clamped indices, no branch per record).  A histogram-free
@@ -2395,39 +2406,32 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
 #pragma unroll
     for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = it * KH_CHUNK_THREADS + tid; r3[it] = from[i < last ? i : last]; }
   }
+  kh_lds_fill16(cnt16, sizeof(cnt16), 0u);
   __syncthreads();
   const bool aborted = s_abort != 0;
-  if (m >= KH_DD_M || aborted) {
+  if (m >= KH_LEAN_M || aborted) {
     if (tid == 0) {
       if (!aborted) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
       __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
-#pragma unroll
-  for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-    const uint32_t i = it * KH_CHUNK_THREADS + tid;
-    kreg[it] = r3[it].klo | ((uint64_t)r3[it].khi << 32);      // (stays in registers for the hash and the duplicate check: two LDS reads less per record)
-    if (i < m) { lk[i] = kreg[it]; lv[i] = r3[it].val; }
-  }
-  KH_STAMP_L(1);
-  kh_lds_fill16(simg, sizeof(simg), 0xFFFFFFFFu);
-  kh_lds_fill16(cnt16, sizeof(cnt16), 0u);
-  __syncthreads();
-  KH_STAMP_L(2);
-  // ---- home counts
+  // ---- records into LDS, home counts (the keys stay in registers for the hash and the duplicate check)
   uint32_t hb[KH_DD_M / KH_CHUNK_THREADS];
 #pragma unroll
   for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+    const uint32_t i = it * KH_CHUNK_THREADS + tid;
+    kreg[it] = r3[it].klo | ((uint64_t)r3[it].khi << 32);
     hb[it] = 0;
-    const uint32_t x = it * KH_CHUNK_THREADS + tid;
-    if (x < m) {
-      hb[it] = (uint32_t)((kh_hash64<HASH>(kreg[it], P.seed) & mask_n) - Sc);
+    if (i < m) {
+      lk[i] = kreg[it]; lv[i] = r3[it].val;
+      hb[it] = (uint32_t)((kh_hash64<HASH>(kreg[it], P.seed) & mask_n) - Sc) & (KH_L - 1u);
       atomicAdd(&cnt16[hb[it] >> 1], 1u << (16 * (hb[it] & 1)));
     }
   }
+  KH_STAMP_L(1);
   __syncthreads();
-  KH_STAMP_L(3);
+  KH_STAMP_L(2);
   uint32_t cb[KH_HOMES_PER_THREAD];
   KhMP32 v; v.A = KH_MP32_NEG; v.n = 0;
 #pragma unroll
@@ -2442,17 +2446,15 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
   const uint32_t n_c = (uint32_t)total.n;      // == m: every record stands for itself
   const long long spill0 = total.A > (long long)KH_L ? total.A - (long long)KH_L : 0;
   const bool early = n_c + KH_XB <= KH_L;
-  KH_STAMP_L(4);
+  KH_STAMP_L(3);
   if (c == 0) {     // circular table: chunk 0 follows the last chunk -> publish, park, and leave the placement to the tail launch
-    // (not placed here, so the group check below never sees it: every record is compared with the records behind it instead --
-    //  one workgroup, once per build)
+    // (not sorted here: every record is compared with the records behind it instead -- one workgroup, once per build)
     bool dup = false;
 #pragma unroll
     for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
       const uint32_t x = it * KH_CHUNK_THREADS + tid;
       if (x < m) {
-        const unsigned long long key = lk[x];
-        for (uint32_t y = x + 1; y < m; ++y) dup = dup || kh_keq(lk[y], key, P.seed.xk);
+        for (uint32_t y = x + 1; y < m; ++y) dup = dup || kh_keq(lk[y], kreg[it], P.seed.xk);
       }
     }
     if (__any(dup) && (tid & 63) == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
@@ -2466,7 +2468,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
     for (uint32_t x = tid; x < m; x += KH_CHUNK_THREADS) { P.ck0[x] = lk[x]; P.cv0[x] = lv[x]; }
     return;
   }
-  // ---- publish / look back (as k_build_fused)
+  // ---- publish (as k_build_fused); the look-back's load is issued here and collected after the duplicate check
+  unsigned long long w0 = 0;
   if (tid == 0) {
     if (c < 64) {     // the first 64 chunks vote on the duplicate ratio (all records distinct here: the vote can only confirm)
       const unsigned long long mine = ((unsigned long long)n_c << 32) | m;
@@ -2481,14 +2484,103 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
       }
     }
     if (early) __hip_atomic_store(&P.pub[c], VALID | ((unsigned long long)spill0 << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t pc = c - 1;
-    unsigned long long w = 0;
+    w0 = __hip_atomic_load(&P.pub[c - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    P.maxidx[c] = 0;
+  }
+  // ---- group starts without the carry-in, record counts in front of every bucket
+  {
+    long long p = excl.A > (long long)excl.n ? excl.A : excl.n;
+    uint32_t np = (uint32_t)excl.n;
+    uint32_t st4[KH_HOMES_PER_THREAD], np4[KH_HOMES_PER_THREAD];
+#pragma unroll
+    for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+      const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+      const long long st = p > (long long)b ? p : (long long)b;
+      st4[j] = (uint32_t)st & 0xFFFFu;         // (< KH_L + 2048: fits 16 bits)
+      np4[j] = np;
+      p = st + cb[j];
+      np += cb[j];
+    }
+    static_assert(KH_HOMES_PER_THREAD == 4, "two packed counter words, one 8-byte store of starts / counts per thread");
+    reinterpret_cast<uint2*>(start0)[tid] = make_uint2(st4[0] | (st4[1] << 16), st4[2] | (st4[3] << 16));
+    reinterpret_cast<uint2*>(npre)[tid] = make_uint2(np4[0] | (np4[1] << 16), np4[2] | (np4[3] << 16));
+    if (tid == KH_CHUNK_THREADS - 1) s_pend = p;      // end of the layout without a carry-in
+    // (the fill counters: every thread owns the two words of its four homes)
+    cnt16[tid * (KH_HOMES_PER_THREAD / 2)] = 0; cnt16[tid * (KH_HOMES_PER_THREAD / 2) + 1] = 0;
+  }
+  __syncthreads();
+  // ---- counting sort by home bucket: rank inside the group from the fill counter
+  uint32_t pj[KH_DD_M / KH_CHUNK_THREADS];       // slot without carry-in (low half) | sorted index (high half) of every record of this lane
+#pragma unroll
+  for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+    pj[it] = 0;
+    const uint32_t x = it * KH_CHUNK_THREADS + tid;
+    if (x < m) {
+      const uint32_t b = hb[it];
+      const uint32_t r = (atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1))) >> (16 * (b & 1))) & 0xFFFFu;
+      uint32_t j = npre[b] + r;
+      if (j >= KH_LEAN_M) j = KH_LEAN_M - 1u;      // (cannot happen with consistent counts; keeps a wild index inside the array)
+      sidx[j] = (uint16_t)x;
+      pj[it] = (start0[b] + r) | (j << 16);
+    }
+  }
+  __syncthreads();
+  KH_STAMP_L(4);
+  {
+    // equal keys share their home bucket, hence sit next to each other in the sorted order: every record compares itself with the
+    // records of its group BEHIND it (0.4 of them on average at load 0.8).  The first KH_DUPK are looked up without a branch (all LDS
+    // reads of a lane in flight together); only groups longer than that (one bucket in 700 at load 0.8) enter the loop
+    bool dup = false;
+    uint32_t jn[KH_DD_M / KH_CHUNK_THREADS], gend[KH_DD_M / KH_CHUNK_THREADS];
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      gend[it] = 0;
+      const uint32_t x = it * KH_CHUNK_THREADS + tid;
+      if (x < m) {
+        const uint32_t b = hb[it];
+        gend[it] = npre[b] + ((cnt16[b >> 1] >> (16 * (b & 1))) & 0xFFFFu);
+        if (gend[it] > KH_LEAN_M) gend[it] = KH_LEAN_M;
+      }
+      jn[it] = (pj[it] >> 16) + 1u;
+    }
+    constexpr uint32_t KH_DUPK = 3;
+    uint32_t ei[KH_DD_M / KH_CHUNK_THREADS][KH_DUPK];
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it)
+#pragma unroll
+      for (uint32_t d = 0; d < KH_DUPK; ++d) ei[it][d] = sidx[jn[it] + d < gend[it] ? jn[it] + d : 0u];
+    bool more = false;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+#pragma unroll
+      for (uint32_t d = 0; d < KH_DUPK; ++d)
+        if (kh_keq(lk[ei[it][d] < KH_LEAN_M ? ei[it][d] : 0u], kreg[it], P.seed.xk) && jn[it] + d < gend[it]) dup = true;
+      jn[it] += KH_DUPK;
+      more = more || jn[it] < gend[it];
+    }
+    while (__any(more)) {
+      more = false;
+#pragma unroll
+      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+        if (jn[it] < gend[it]) {
+          const uint32_t e = sidx[jn[it]];
+          if (kh_keq(lk[e < KH_LEAN_M ? e : 0u], kreg[it], P.seed.xk)) dup = true;
+          ++jn[it];
+          more = more || jn[it] < gend[it];
+        }
+      }
+    }
+    if (__any(dup) && (tid & 63) == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+  }
+  KH_STAMP_L(5);
+  // ---- look back: the word requested above, or a poll if the chunk before had not published yet
+  if (tid == 0) {
+    unsigned long long w = w0;
     const long long t0 = clock64();
-    for (;;) {
-      w = __hip_atomic_load(&P.pub[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (w & VALID) break;
+    while (!(w & VALID)) {
       if (clock64() - t0 > P.poll_limit) { atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u); w = VALID; break; }   // bounded: then the general path
       __builtin_amdgcn_s_sleep(4);
+      w = __hip_atomic_load(&P.pub[c - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const uint32_t x = (uint32_t)((w >> 32) & 0x7FFFFFFFu);
     if (x > KH_XB) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);       // a carry chain: general path
@@ -2498,38 +2590,21 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
       const long long sp = pe > (long long)KH_L ? pe - (long long)KH_L : 0;
       __hip_atomic_store(&P.pub[c], VALID | ((unsigned long long)sp << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    s_x = x;
-    P.maxidx[c] = 0;
+    s_x = x > KH_XB ? 0u : x;          // (flagged: the result is discarded; keep the positions inside what the image and the counters assume)
   }
+  __syncthreads();                      // (also: the sort arrays are dead, the slot image takes their place)
+  KH_STAMP_L(6);
+  kh_lds_fill16(simg, (KH_L + KH_FSPILL) * 2u, 0xFFFFFFFFu);
   __syncthreads();
-  KH_STAMP_L(5);
-  // ---- placement with the carry-in
-  const long long xr = (long long)s_x;
-  long long p = excl.A > xr + excl.n ? excl.A : xr + excl.n;
-  uint32_t st4[KH_HOMES_PER_THREAD];
-#pragma unroll
-  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
-    const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
-    const long long st = p > (long long)b ? p : (long long)b;
-    st4[j] = (uint32_t)st & 0xFFFFu;         // (< KH_L + KH_XB + 2048: fits 16 bits)
-    p = st + cb[j];
-  }
-  reinterpret_cast<uint2*>(start)[tid] = make_uint2(st4[0] | (st4[1] << 16), st4[2] | (st4[3] << 16));      // (the four starts of a lane: one 8-byte store)
-  if (tid == KH_CHUNK_THREADS - 1) s_pend = p;
-  // (the fill counters: every thread owns the two words of its four homes)
-  cnt16[tid * (KH_HOMES_PER_THREAD / 2)] = 0; cnt16[tid * (KH_HOMES_PER_THREAD / 2) + 1] = 0;
-  static_assert(KH_HOMES_PER_THREAD == 4, "two packed counter words per thread");
-  __syncthreads();
-  uint32_t pr[KH_DD_M / KH_CHUNK_THREADS];       // slot (relative to the chunk) every record of this lane went to
+  // ---- slot image with the carry-in: slot = max(slot without it, carry + sorted index)
+  const uint32_t xr = s_x;
 #pragma unroll
   for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-    pr[it] = 0;
     const uint32_t x = it * KH_CHUNK_THREADS + tid;
     if (x < m) {
       const uint32_t b = hb[it];
-      const uint32_t r = (atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1))) >> (16 * (b & 1))) & 0xFFFFu;
-      const uint32_t prel = start[b] + r;
-      pr[it] = prel;
+      const uint32_t p0 = pj[it] & 0xFFFFu, pc = (pj[it] >> 16) + xr;
+      const uint32_t prel = p0 > pc ? p0 : pc;
       uint32_t dist = prel - b;
       if (KIND == KHK_RH && dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
       if (prel < KH_L + KH_FSPILL) simg[prel] = (uint16_t)(x | ((dist < 31u ? dist : 31u) << 11));   // record index | distance code
@@ -2537,55 +2612,10 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
     }
   }
   __syncthreads();
-  KH_STAMP_L(6);
-  {
-    // equal keys share their home bucket, hence sit in one group of consecutive slots [start[b], start[b] + size[b]): every element
-    // compares itself with the elements of its group BEHIND it (as k_build_fused's nodup check)
-    bool dup = false;
-    uint32_t gend[KH_DD_M / KH_CHUNK_THREADS];
-#pragma unroll
-    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-      gend[it] = 0;
-      const uint32_t x = it * KH_CHUNK_THREADS + tid;
-      if (x < m) {
-        const uint32_t b = hb[it];
-        gend[it] = start[b] + ((cnt16[b >> 1] >> (16 * (b & 1))) & 0xFFFFu);
-        if (gend[it] > KH_L + KH_FSPILL) { dup = true; gend[it] = 0; }       // part of the group went past the image: cannot be checked here
-      }
-      ++pr[it];
-    }
-    constexpr uint32_t KH_DUPK = 3;
-    uint32_t ei[KH_DD_M / KH_CHUNK_THREADS][KH_DUPK];
-#pragma unroll
-    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it)
-#pragma unroll
-      for (uint32_t d = 0; d < KH_DUPK; ++d) ei[it][d] = simg[pr[it] + d < gend[it] ? pr[it] + d : 0u] & 0x7FFu;
-    bool more = false;
-#pragma unroll
-    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-#pragma unroll
-      for (uint32_t d = 0; d < KH_DUPK; ++d)
-        if (kh_keq(lk[ei[it][d]], kreg[it], P.seed.xk) && pr[it] + d < gend[it]) dup = true;
-      pr[it] += KH_DUPK;
-      more = more || pr[it] < gend[it];
-    }
-    while (__any(more)) {
-      more = false;
-#pragma unroll
-      for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
-        if (pr[it] < gend[it]) {
-          if (kh_keq(lk[simg[pr[it]] & 0x7FFu], kreg[it], P.seed.xk)) dup = true;
-          ++pr[it];
-          more = more || pr[it] < gend[it];
-        }
-      }
-    }
-    if (__any(dup) && (tid & 63) == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
-  }
-  KH_STAMP_L(7);
   long long pend = s_pend;
+  if (pend < (long long)xr + n_c) pend = (long long)xr + n_c;
   if (pend < (long long)KH_L) pend = KH_L;
-  const uint32_t lo = (uint32_t)xr;
+  const uint32_t lo = xr;
   const uint32_t hi = pend < (long long)(KH_L + KH_FSPILL) ? (uint32_t)pend : (KH_L + KH_FSPILL);
   for (uint32_t s0 = lo + tid; s0 < hi; s0 += KH_CHUNK_THREADS) {
     KhSlot* dst = P.New.s + ((Sc + s0) & mask_n);
@@ -2606,7 +2636,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
       kh_slot_st(dst, key, lv[x], ib);
     }
   }
-  KH_STAMP_L(8);
+  KH_STAMP_L(7);
 }
 
 // carry-in of chunk 0 = run-over of the last chunk (circular table)
