@@ -359,6 +359,7 @@ kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw
     else if (src == 0) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 0>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 1) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 3) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 3>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }      // (batch erase: Robin Hood only)
+    else if (src == 4) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_erase_stream<HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }              // (batch erase as an ordered stream)
     else { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); } }
   { Launch L(t, "k_fused_totals");
     hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
@@ -1383,7 +1384,10 @@ kh_status erase_core(kh_table* t, const void* keys, uint64_t n, kh_mem where, ui
     F.PB = PBe; F.mode = KH_DEDUP_ERASE;
     F.R.Old = t->cur; F.R.PB = PBe;
     FusedRun run;
-    { kh_status fs = launch_fused(t, 3, F, nw, PBe, "k_erase_fused", &run); t->part_overflow = nullptr; if (fs != KH_OK) return fs; }
+    // (erase keys of a chunk fit one per lane -- a histogram-free partition's slot, or the mean of an exact one leaves room: the ordered-stream
+    //  kernel, four workgroups per CU; else the staging form)
+    const bool ordered = (R.slot != 0 ? R.slot <= KH_ES_MAXK : n / (uint64_t(1) << PBe) <= KH_ES_MAXK / 2) && !getenv("KH_DISABLE_ORDERED_ERASE");
+    { kh_status fs = launch_fused(t, ordered ? 4 : 3, F, nw, PBe, "k_erase_fused", &run); t->part_overflow = nullptr; if (fs != KH_OK) return fs; }
     const uint32_t* ff = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t->hpin) + 64);
     bool bad = R.overflow && (uint32_t)t->hpin[30];
     for (int i = 0; i < KH_NFLAGS; ++i) bad = bad || ff[i] != 0;

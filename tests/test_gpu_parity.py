@@ -1300,6 +1300,53 @@ def test_batch_erase_streaming_form_and_its_fall_back(oracle, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("hname,hid", [("murmur3avx64", 1), ("farm", 3)])
+def test_batch_erase_as_an_ordered_stream(oracle, monkeypatch, hname, hid):
+    """the ordered-stream form of the Robin Hood batch erase (k_erase_stream: a chunk's slots scanned in slot order, survivors stored at
+    max(home, slot of the one before + 1)): a table of 2^23 buckets (histogram-free partition of the erase keys), hits, misses and keys given
+    twice; a second and a third batch on the table the first one left (the third empties most chunks); the staging form on the same input
+    (test hook) leaves the same table; a bimolecule table erased by the other strand.  Info bytes, sizes, capacities, key / value sets and
+    query results against the oracle."""
+    n = 5_000_000
+    keys = W.distinct_u64(n, seed=61); vals = np.arange(n, dtype=np.uint32)
+    e1 = np.concatenate([keys[:600_000], W.distinct_u64(100_000, seed=98), keys[:50_000]])
+    e1 = e1[W.shuffle_perm(len(e1), 3)]
+    e2 = keys[400_000:1_700_000]                      # 2*10^5 of them are gone already
+    e3 = keys[1_700_000:3_100_000][::-1].copy()
+    for ordered in (True, False):
+        if not ordered:
+            monkeypatch.setenv("KH_DISABLE_ORDERED_ERASE", "1")
+        g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=hname); o = oracle.OracleTable(0, 128, 0.35, 0.8, hid, 43)
+        assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals) and g.capacity() == 1 << 23
+        g.profile_enable(True)
+        for e in ((e1, e2, e3) if ordered else (e1,)):
+            assert g.erase(dev(e)) == o.erase(e)
+            check_state(g, o, 0)
+        p = g.profile()
+        assert "k_erase_fused" in p and "k_erase_mark" not in p, p
+        check_queries(g, o, np.concatenate([keys[:3000], keys[2_000_000:2_003_000], keys[4_000_000:4_003_000]]))
+        if ordered:                                     # the table goes on working: new keys into the gaps, another erase
+            more = W.distinct_u64(300_000, seed=62); mv = np.arange(300_000, dtype=np.uint32)
+            assert g.insert(dev(more), dev(mv)) == o.insert(more, mv)
+            assert g.erase(dev(more[:100_000])) == o.erase(more[:100_000]) == 100_000
+            check_state(g, o, 0)
+        g.close()
+    monkeypatch.delenv("KH_DISABLE_ORDERED_ERASE")
+    k = 31
+    kk = W.distinct_u64(4_500_000, seed=63) & np.uint64((1 << (2 * k)) - 1)
+    kk = kk[np.unique(np.minimum(kk, _revcomp(kk, k)), return_index=True)[1]]      # one strand per k-mer
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=hname); g.set_key_transform(k)
+    o = oracle.OracleTable(0, 128, 0.35, 0.8, hid, 43); o.set_key_transform(k)
+    vv = np.arange(len(kk), dtype=np.uint32)
+    assert g.insert(dev(kk), dev(vv)) == o.insert(kk, vv) and g.capacity() == 1 << 23
+    er = np.concatenate([_revcomp(kk[:300_000], k), kk[1_000_000:1_200_000], _revcomp(kk[:20_000], k)])
+    g.profile_enable(True)
+    assert g.erase(dev(er)) == o.erase(er) == 500_000
+    assert "k_erase_fused" in g.profile() and "k_erase_mark" not in g.profile()
+    check_state(g, o, 0)
+    g.close()
+
+
 @pytest.mark.parametrize("kname,cls,kind", KINDS)
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_sequences_with_reducer_plus_and_aborts(oracle, kname, cls, kind, seed):

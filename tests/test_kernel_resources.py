@@ -32,11 +32,14 @@ def test_no_scratch_no_spills(resources):
             # per wave and ~30 of its ~105 scalars live in vector lanes instead (v_writelane / v_readlane, no memory): measured 6 % faster
             # insert than 3 workgroups per CU without spills
             assert r.get("SGPRSpill", 0) <= 40 and r["Occupancy"] >= 8 and r["LDS"] <= 40960, (name, r)
+        elif "k_erase_stream" in name:
+            # the ordered-stream batch erase: four workgroups per CU as well (no spills at 64 VGPRs, 37.5 KB of LDS)
+            assert r.get("SGPRSpill", 0) == 0 and r["Occupancy"] >= 8 and r["LDS"] <= 40960, (name, r)
         elif "k_ip_serial" not in name and "k_small_batch" not in name and not ("k_find" in name and "Lb1E" in name):
             assert r.get("SGPRSpill", 0) == 0, (name, r)
 
 
-@pytest.mark.parametrize("kernel,min_occ", [("k_build_fused", 6), ("k_build_lean", 8), ("k_dedup", 6), ("k_chunk_place", 6), ("k_part_scatter", 4)])
+@pytest.mark.parametrize("kernel,min_occ", [("k_build_fused", 6), ("k_build_lean", 8), ("k_erase_stream", 8), ("k_dedup", 6), ("k_chunk_place", 6), ("k_part_scatter", 4)])
 def test_lds_bound_kernels_keep_their_occupancy(resources, kernel, min_occ):
     hits = {n: r for n, r in resources.items() if kernel + "I" in n}
     assert hits, kernel
