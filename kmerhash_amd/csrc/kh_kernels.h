@@ -2647,12 +2647,13 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_build_lean(KhFusedParam
 // load and store of a wave is 1 KB), looks each element up in the chunk's erase keys (chained per home bucket in LDS; home from the info
 // byte, no hash), the scan runs through DPP, the survivors enter themselves into an image of the new chunk in LDS and the rows are stored
 // from there (every slot once, coalesced: survivors stored straight from registers, empties in a second sweep, left half-written lines
-// behind and ran no faster than the staging form).  37 KB of LDS, 60 VGPRs: four workgroups per CU; 0.84-0.9 ms for 10^7 of 10^8 keys = the
+// behind and ran no faster than the staging form).  40.8 KB of LDS, <= 64 VGPRs: four workgroups per CU; 0.84-0.9 ms for 10^7 of 10^8 keys = the
 // 4.4 GB it moves at 5 TB/s, against 1.05-1.15 ms of k_build_fused<.., 3>, which it replaces wherever a chunk's erase keys fit one per lane
 // (same protocol: granules with early publication, one-deep look-back, chunk 0 parked for the tail launch, flags -> the caller's mark +
 // re-layout path); survivors whose slot cannot depend on the carry-in are laid out before the look-back's word is collected.
 // ---------------------------------------------------------------------------------------------
-#define KH_ES_MAXK 512u          // erase keys one chunk may receive (slot of the histogram-free partition: checked by the host)
+#define KH_ES_MAXK 832u          // erase keys one chunk may receive (slot of the histogram-free partition: checked by the host); two per lane at most.
+                                 // (832: the reference benchmark's own shape -- 10^7 keys out of a 2^25-bucket table, slots of 799 -- fits, and so does the LDS: 40.8 KB)
 // inclusive (max,+) scan over the 64 lanes of a wave through DPP (see kh_mp32_dpp_step)
 __device__ __forceinline__ KhMP32 kh_wave_scan_mp32(KhMP32 v) {
   v = kh_mp32_dpp_step<0x111, 0xF>(v);
@@ -2710,6 +2711,8 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_erase_stream(KhFusedPar
   const uint64_t* src8 = kcount ? reinterpret_cast<const uint64_t*>(P.src.rec[0]) + kb : reinterpret_cast<const uint64_t*>(old);      // (no key: any valid address)
   const uint32_t klast = kcount ? (uint32_t)(kcount < KH_ES_MAXK ? kcount : KH_ES_MAXK) - 1u : 0u;
   const unsigned long long mykey = src8[tid < klast ? tid : klast];
+  const unsigned long long mykey2 = src8[tid + KH_CHUNK_THREADS < klast ? tid + KH_CHUNK_THREADS : klast];
+  static_assert(KH_ES_MAXK <= 2 * KH_CHUNK_THREADS, "two erase keys per lane");
   if (fixed) {
 #pragma unroll
     for (uint32_t k = 0; k < ROWS; ++k) if (k < nrows) w[k] = kh_slot_ld(old + ((Sc + base + 64u * k) & mask_n));
@@ -2729,6 +2732,12 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_erase_stream(KhFusedPar
     ek[tid] = mykey;
     const uint32_t b = (uint32_t)((kh_hash64<HASH>(mykey, P.seed) & mask_n) - Sc) & (KH_L - 1u);
     enext[tid] = (uint16_t)atomicExch(&ehead[b & (EH - 1u)], tid + 1u);
+  }
+  if (tid + KH_CHUNK_THREADS < m_e) {
+    const uint32_t i = tid + KH_CHUNK_THREADS;
+    ek[i] = mykey2;
+    const uint32_t b = (uint32_t)((kh_hash64<HASH>(mykey2, P.seed) & mask_n) - Sc) & (KH_L - 1u);
+    enext[i] = (uint16_t)atomicExch(&ehead[b & (EH - 1u)], i + 1u);
   }
   __syncthreads();
   // ---- (max,+) scan in slot order: row by row inside the wave (DPP), the waves' totals through LDS.  A slot counts if it holds an element

@@ -1312,7 +1312,7 @@ def test_batch_erase_as_an_ordered_stream(oracle, monkeypatch, hname, hid):
     e1 = np.concatenate([keys[:600_000], W.distinct_u64(100_000, seed=98), keys[:50_000]])
     e1 = e1[W.shuffle_perm(len(e1), 3)]
     e2 = keys[400_000:1_700_000]                      # 2*10^5 of them are gone already
-    e3 = keys[1_700_000:3_100_000][::-1].copy()
+    e3 = keys[1_700_000:3_900_000][::-1].copy()      # ~540 keys per chunk: two per lane in k_erase_stream (slots of 715 <= 832)
     for ordered in (True, False):
         if not ordered:
             monkeypatch.setenv("KH_DISABLE_ORDERED_ERASE", "1")
