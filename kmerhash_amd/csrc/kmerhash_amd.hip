@@ -355,7 +355,11 @@ kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw
   F.R.New = nw; F.R.seed = t->seed; F.R.flags = F.flags;
   { Launch L(t, name);
     // (the benchmark case -- a duplicate-free sample, one source of 12-byte records -- has its own kernel with 17 KB less LDS: 4 workgroups per CU)
-    if (src == 0 && F.nodup && F.src.rec12 == 1 && F.src.n == 1 && !g_disable_lean) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_lean<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
+    // (... as long as a chunk of mean + 5 sigma records fits its smaller staging arrays: a table filled to 0.9 would fail it in a chunk or two
+    //  of 65536 and pay for the discarded launch)
+    const double mean_c = (double)F.n_total / (double)nch;
+    const bool lean_fits = mean_c + 5.0 * std::sqrt(mean_c) < (double)KH_LEAN_M;
+    if (src == 0 && F.nodup && F.src.rec12 == 1 && F.src.n == 1 && lean_fits && !g_disable_lean) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_lean<KIND, HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 0) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 0>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 1) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 3) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 3>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }      // (batch erase: Robin Hood only)

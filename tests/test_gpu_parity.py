@@ -1300,6 +1300,24 @@ def test_batch_erase_streaming_form_and_its_fall_back(oracle, monkeypatch):
     g.close()
 
 
+def test_bulk_build_of_a_table_filled_to_0_9(oracle):
+    """max load factor 0.9, filled to the threshold exactly (7 549 747 keys -> 2^23 buckets, 1843 records per chunk on average): the lean bulk
+    build's staging arrays (2016 records) would be too small for a chunk or two of 4096, so the build goes to k_build_fused -- ONE launch, no
+    discarded attempt, no general path -- and equals the oracle; at 0.8 the same call takes the lean kernel (k_build_fused is the profile name
+    of both; KH_DISABLE_LEAN_BUILD gives the same table)."""
+    cap = 1 << 23
+    n = int(np.float32(cap) * np.float32(0.9))
+    keys = W.distinct_u64(n, seed=71); vals = np.arange(n, dtype=np.uint32)
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.9); o = oracle.OracleTable(0, 128, 0.35, 0.9)
+    g.profile_enable(True)
+    assert g.insert(dev(keys), dev(vals)) == o.insert(keys, vals) == n and g.capacity() == cap
+    p = g.profile()
+    assert p["k_build_fused"][0] == 1 and "k_dedup" not in p and p["k_part_scatter"][0] == 2, p
+    check_state(g, o, 0)
+    check_queries(g, o, np.concatenate([keys[:4000], W.distinct_u64(4000, seed=72)]))
+    g.close()
+
+
 @pytest.mark.parametrize("hname,hid", [("murmur3avx64", 1), ("farm", 3)])
 def test_batch_erase_as_an_ordered_stream(oracle, monkeypatch, hname, hid):
     """the ordered-stream form of the Robin Hood batch erase (k_erase_stream: a chunk's slots scanned in slot order, survivors stored at
