@@ -1300,6 +1300,53 @@ def test_batch_erase_streaming_form_and_its_fall_back(oracle, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("hname,hid", [("murmur3avx64", 1), ("farm", 3)])
+def test_duplicate_heavy_batches_into_a_loaded_table(oracle, hname, hid):
+    """duplicate-heavy batches into a loaded Robin Hood table on the general path (k_dedup: ~370 distinct keys per partition, half of them
+    already in the 3*10^6-key table, every key three times): as a first-wins insert, as an update, as a reducer-plus insert with values
+    and as a counting insert (8-byte records); key / value sets against the oracle and a numpy model, info bytes against the oracle.
+    (Written for a variant of k_dedup that read the keys' chunk of the table as a stream instead of probing it key by key -- correct, but no
+    faster: the probes of one partition already share their chunk's sectors in L2 -- and kept as a parity case of this shape.)"""
+    n0 = 3_000_000
+    base = W.distinct_u64(n0, seed=81); bv = np.arange(n0, dtype=np.uint32)
+    fresh = W.distinct_u64(1_500_000, seed=82)
+    dist = np.concatenate([base[:1_500_000], fresh])
+    batch = np.concatenate([dist, dist[::-1], dist])[W.shuffle_perm(3 * len(dist), 5)]
+    vals = (np.arange(len(batch), dtype=np.uint64) * np.uint64(2654435761) % np.uint64(2**32)).astype(np.uint32)
+    # first-wins insert
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=hname); o = oracle.OracleTable(0, 128, 0.35, 0.8, hid, 43)
+    assert g.insert(dev(base), dev(bv)) == o.insert(base, bv)
+    g.profile_enable(True)
+    assert g.insert(dev(batch), dev(vals)) == o.insert(batch, vals) == 1_500_000
+    assert "k_dedup" in g.profile(), g.profile()          # (9*10^6 pairs predict four times the capacity: the general path)
+    check_state(g, o, 0)
+    # update of the same keys: every one of them is in the table now, the last value of the batch wins
+    g.update(dev(batch), dev(vals))
+    ok, ov = o.sorted_items()
+    uk, first_rev = np.unique(batch[::-1], return_index=True)
+    ov = ov.copy(); ov[np.searchsorted(ok, uk)] = vals[::-1][first_rev]
+    sk, sv = g.sorted_items()
+    assert np.array_equal(sk, ok) and np.array_equal(sv, ov)
+    assert g.size() == o.size() and g.capacity() == o.capacity() and np.array_equal(g.export_info(), o.export_info())
+    g.close()
+    # reducer plus with values, then a counting insert (no values: 8-byte records)
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash=hname); o = oracle.OracleTable(0, 128, 0.35, 0.8, hid, 43)
+    g.insert(dev(base), dev(bv)); o.insert(base, bv)
+    assert g.insert_reduce_plus(dev(batch), dev(vals)) == 1_500_000
+    o.insert(batch, np.zeros(len(batch), dtype=np.uint32))
+    assert g.insert_reduce_plus(dev(batch)) == 0
+    uk, inv = np.unique(batch, return_inverse=True)
+    add = np.zeros(len(uk), dtype=np.uint64); np.add.at(add, inv, vals.astype(np.uint64) + np.uint64(1))
+    exp = dict(zip(base.tolist(), bv.tolist()))
+    for k, a in zip(uk.tolist(), add.tolist()):
+        exp[k] = (exp.get(k, 0) + a) & 0xFFFFFFFF
+    sk, sv = g.sorted_items()
+    ek = np.array(sorted(exp), dtype=np.uint64)
+    assert np.array_equal(sk, ek) and np.array_equal(sv, np.array([exp[int(k)] for k in ek], dtype=np.uint32))
+    assert g.size() == o.size() and g.capacity() == o.capacity() and np.array_equal(g.export_info(), o.export_info())
+    g.close()
+
+
 def test_bulk_build_of_a_table_filled_to_0_9(oracle):
     """max load factor 0.9, filled to the threshold exactly (7 549 747 keys -> 2^23 buckets, 1843 records per chunk on average): the lean bulk
     build's staging arrays (2016 records) would be too small for a chunk or two of 4096, so the build goes to k_build_fused -- ONE launch, no
