@@ -10,7 +10,10 @@
 //     chunks is a (max,+) carry with a one-deep look-back.  k_build_fused does all of that in ONE launch, from partition records
 //     (SRC 0: bulk build into an empty table), from the table itself (SRC 1: rehash / reserve / the erase fall-back), from both
 //     folded together in LDS (SRC 2: insert into a non-empty table) or from the table minus the chunk's erase keys (SRC 3: batch
-//     erase).  The general path is k_dedup -> k_chunk_count -> k_chunk_carry -> k_chunk_place.
+//     erase).  The benchmark case of SRC 0 (distinct keys, one source of 12-byte records) has its own kernel, k_build_lean (four
+//     workgroups per CU; sort without the carry-in, look-back collected late), and so has the batch erase: k_erase_stream scans the
+//     chunk's slots IN SLOT ORDER (a Robin Hood table is sorted by home bucket already) -- no staging, counting or ranking.
+//     The general path is k_dedup -> k_chunk_count -> k_chunk_carry -> k_chunk_place.
 //   * Batches of <= 16 keys are applied in place by one lane (k_small_batch), mid-size batches in place by one lane per region of
 //     512 slots (k_ip_bin / k_ip_apply / k_ip_serial).
 //   * Read-only batches (k_find: find, count) probe the table one 64-byte SECTOR (4 aligned slots) at a time, four queries per lane
