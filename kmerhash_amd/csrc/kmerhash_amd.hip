@@ -513,33 +513,35 @@ struct Partitioned {
   int rec12;                                    // 0: 16-byte records; 1: 12-byte (key, value) (histogram-free layout only); 2: 8-byte keys (counting insert)
 };
 // slot of a histogram-free partition with mean m records: m + 7 sigma (hashed keys: Poisson) + a little
-inline uint64_t slack_slot(double mean) { return (uint64_t)(mean + 7.0 * std::sqrt(mean) + 16.0); }
+// (vf: variance of a partition's fill over its mean -- 1 for distinct keys (Poisson in the records); a batch with duplicates fills its partitions
+//  key by key, E[m^2] / E[m] records at a time: insert_core estimates that factor from the duplicate sample)
+inline uint64_t slack_slot(double mean, double vf = 1.0) { return (uint64_t)(mean + 7.0 * std::sqrt(mean * vf) + 16.0); }
 const bool g_disable_slack = getenv("KH_DISABLE_SLACK_PARTITION") != nullptr;      // test hook: exact offsets always
 // eight consecutive partition tiles per XCD (blocks b, b + 8, ... share one): the adjacent output runs of consecutive tiles meet in
 // one L2 (-3 % scatter time, measured A/B); KH_DISABLE_XCD_SWIZZLE=1 turns it off
 const int g_xcd_swizzle = getenv("KH_DISABLE_XCD_SWIZZLE") ? 0 : 1;
 // records the two buffers of partition_batch must hold
-inline uint64_t part_buffer_records(uint64_t n, uint32_t PB, bool allow_slack) {
+inline uint64_t part_buffer_records(uint64_t n, uint32_t PB, bool allow_slack, double vf = 1.0) {
   if (!allow_slack || g_disable_slack || PB <= 11 || n < (uint64_t(256) << PB)) return n;
-  return (slack_slot((double)n / (double)(uint64_t(1) << PB)) << PB) + KH_PART_TILE;        // slots + the dump area of the scatter
+  return (slack_slot((double)n / (double)(uint64_t(1) << PB), vf) << PB) + KH_PART_TILE;        // slots + the dump area of the scatter
 }
 
 // Partitions n input pairs into `fin` (n records); `tmp` (n records) is scratch for the first of two passes.  idx_base =
 // stream position of the first pair (pairs fed before it in a streamed insert).  Asynchronous on the table's stream.
 kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, const char* vbase, uint32_t vstride,
                           uint32_t vconst, uint64_t n, uint64_t idx_base, uint32_t PB, ulonglong2* tmp, ulonglong2* fin, Partitioned& out,
-                          bool allow_slack = false, int rec12 = 0, const SlackShared* shared = nullptr, bool force_slack = false) {
+                          bool allow_slack = false, int rec12 = 0, const SlackShared* shared = nullptr, bool force_slack = false, double vf = 1.0) {
   const uint32_t nparts = 1u << PB;
   out.slot = 0; out.cursor = nullptr; out.overflow = nullptr; out.rec12 = 0;
   // (force_slack: the caller has sized tmp / fin for the fixed slots itself -- (slack_slot(n / 2^PB) << PB) + KH_PART_TILE records each --
   //  whatever n is: the erase keys of a batch erase, where the histogram sweep would cost more than the partition)
-  if (shared || force_slack || part_buffer_records(n, PB, allow_slack) != n) {
+  if (shared || force_slack || part_buffer_records(n, PB, allow_slack, vf) != n) {
     // ---- histogram-free two-pass partition: hashed keys fill the 2^PB partitions evenly, so every partition
     // gets a fixed slot of mean + 7 sigma records and the passes reserve space with their cursors alone: no histogram sweep
     // over the keys (0.33 ms per 1e8), no offset scan.  Level-1 buckets are the unions of their partitions' slots.
     const uint32_t B1 = (PB + 1) / 2, B2 = PB - B1, nb1 = 1u << B1, nb2 = 1u << B2;
     // (a piece of a streamed insert: its level-1 buckets are sized for the piece, the final slots -- shared -- for the whole batch)
-    const uint64_t slot = shared ? shared->slot : slack_slot((double)n / (double)nparts);
+    const uint64_t slot = shared ? shared->slot : slack_slot((double)n / (double)nparts, vf);
     const uint64_t slot1 = shared ? slack_slot((double)n / (double)nb1) : slot * nb2;
     unsigned long long *cur1, *cur2; uint64_t* starts; uint32_t* ovf;
     TAKE(cur1, unsigned long long, nb1);
@@ -549,7 +551,7 @@ kh_status partition_batch(kh_table* t, const char* kbase, uint32_t kstride, cons
     // level-1 bucket's fill, which is well inside the slot (the union of its partitions' slots: 256 x 7 sigma of THEIR fill); a bucket
     // that holds more raises the overflow flag like a slot that runs over
     const double mean1 = (double)n / (double)nb1;
-    const uint64_t fill_cap = std::min<uint64_t>(slot1, (uint64_t)(mean1 + 9.0 * std::sqrt(mean1) + 16.0));
+    const uint64_t fill_cap = std::min<uint64_t>(slot1, (uint64_t)(mean1 + 9.0 * std::sqrt(mean1 * vf) + 16.0));
     const uint32_t tps = (uint32_t)((fill_cap + KH_PART_TILE - 1) / KH_PART_TILE);
     const uint32_t max_tiles = nb1 * tps;
     if (shared) hipLaunchKernelGGL(k_init_cursors, dim3((nb1 + 255) / 256), dim3(256), 0, t->stream, cur1, (uint64_t*)nullptr, (uint64_t)nb1, slot1);
@@ -708,6 +710,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
   const size_t keep_blk = t->blk, keep_off = t->off;
   int first_attempt = 0;
   bool dup_heavy = false;
+  double vf = 1.0;            // variance factor of the histogram-free slots (duplicates: see below)
   if (part_buffer_records(n, PB, true) != n) {
     // histogram-free partition only for batches a sample finds (nearly) free of duplicates
     unsigned long long* sset; uint32_t* dups;
@@ -722,13 +725,25 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     // that are Poisson in the number of RECORDS, and already a mean multiplicity of 1.5 (a k-mer counter's file batch at low coverage:
     // ~7 duplicate pairs in the sample, birthday-bound) widens them enough to overflow a slot somewhere among 2^19 partitions --
     // measured: every such batch paid a discarded 7.5 ms partition attempt; the histogram sweep of the exact path costs 2.5 ms
-    if ((uint32_t)t->hpin[31] >= 1u) { first_attempt = 1; dup_heavy = true; }
-    t->batch_nodup = (uint32_t)t->hpin[31] == 0u;
+    // ... UNLESS the slots are sized for the duplicates: a partition then fills key by key, E[m^2] / E[m] records at a time, and that factor
+    // follows from the sample -- d duplicates among S sampled keys of n say sum m (m - 1) / n = 2 n d / S^2 (the reference benchmark's x5.5 input:
+    // 129 duplicates -> 7.0; a k-mer counter's batch at coverage 1.5: 7 -> 2.5).  Taken at its upper end (d + 3 sqrt(d) + 3) and only while the
+    // slot stays below twice the mean; an overflow after all repeats the batch with exact offsets as before.
+    const uint32_t dsample = (uint32_t)t->hpin[31];
+    if (dsample >= 1u) {
+      dup_heavy = true;
+      const double d_ub = (double)dsample + 3.0 * std::sqrt((double)dsample) + 3.0;
+      const double f = 1.0 + 2.0 * (double)n * d_ub / ((double)KH_SAMPLE_N * (double)KH_SAMPLE_N);
+      const double mean = (double)n / (double)(uint64_t(1) << PB);
+      if (!getenv("KH_DISABLE_DUP_SLACK") && (double)slack_slot(mean, f) <= 2.0 * mean) vf = f;
+      else first_attempt = 1;
+    }
+    t->batch_nodup = dsample == 0u;
     t->blk = keep_blk; t->off = keep_off;
   } else first_attempt = 1;
   for (int attempt = first_attempt; attempt < 2; ++attempt) {
     const bool slack = attempt == 0;          // histogram-free first; exact offsets if a partition outgrew its slot (skewed keys)
-    const uint64_t m = part_buffer_records(n, PB, slack);
+    const uint64_t m = part_buffer_records(n, PB, slack, vf);
     if (!slack && attempt == 1) { t->blk = keep_blk; t->off = keep_off; }
     // no duplicate in the sample and an empty table ahead of the one-launch build: the records need no stream position
     // (12 bytes instead of 16); whatever that build cannot take (a duplicate after all, a dense chunk) repeats the batch
@@ -736,7 +751,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     // a counting insert (Reducer = std::plus, every value 1) of a batch the sample found heavy in duplicates -- the k-mer counter's
     // batches: the records are the keys alone (8 bytes: neither value nor position is needed), and the general path takes them
     // directly (the one-launch forms speculate on few duplicates: hopeless here)
-    const bool rec8 = !slack && !rec12 && dup_heavy && mode == INS_PLUS && vbase == nullptr && !getenv("KH_DISABLE_REC8");
+    const bool rec8 = !rec12 && dup_heavy && mode == INS_PLUS && vbase == nullptr && !getenv("KH_DISABLE_REC8");
     const int kind = rec12 ? 1 : rec8 ? 2 : 0;
     ulonglong2 *tmp, *fin, *spare;
     { char *a, *b; const size_t rb = kind == 1 ? sizeof(KhRec12) : kind == 2 ? sizeof(KhRec8) : sizeof(ulonglong2);
@@ -744,7 +759,7 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
       tmp = reinterpret_cast<ulonglong2*>(a); fin = reinterpret_cast<ulonglong2*>(b); spare = tmp;
       if (kind == 2) { char* c; TAKE(c, char, m * 12); spare = reinterpret_cast<ulonglong2*>(c); } }     // (lists of distinct keys + counts: 12 bytes per entry)
     Partitioned R;
-    kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R, slack, kind);
+    kh_status st = partition_batch(t, kbase, kstride, vbase, vstride, mode == INS_PLUS ? 1u : 0u, n, 0, PB, tmp, fin, R, slack, kind, nullptr, false, vf);
     if (st != KH_OK) return st;
     KhSrcSet S;
     memset(&S, 0, sizeof(S));
@@ -895,7 +910,18 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   if (plus_live) TAKE(D.cnt_upd, uint32_t, R.nparts);
   // with exact partition offsets nothing can discard the attempt before the re-layout: the sums are added inside k_dedup (its
   // membership probes have the slot in hand) and the list only serves to take them back should the re-layout fail
-  D.plus_immediate = (plus_live && t->part_overflow == nullptr && !getenv("KH_DISABLE_PLUS_IMMEDIATE")) ? 1 : 0;
+  // ... and so they are behind a histogram-free partition once its overflow flag has been read clean: the partition is complete in stream
+  // order, so the flag is final -- one small copy + wait (tens of microseconds) instead of a k_apply_plus pass at random over the table
+  // (7 ms per 4.5e8-k-mer batch of the k-mer counter, measured)
+  bool overflow_clean = t->part_overflow == nullptr;
+  if (plus_live && !overflow_clean && !getenv("KH_DISABLE_PLUS_IMMEDIATE")) {
+    t->hpin[30] = 0;
+    HIPCHK(hipMemcpyAsync(t->hpin + 30, t->part_overflow, 4, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if ((uint32_t)t->hpin[30]) return KH_RETRY_EXACT;
+    overflow_clean = true;
+  }
+  D.plus_immediate = (plus_live && overflow_clean && !getenv("KH_DISABLE_PLUS_IMMEDIATE")) ? 1 : 0;
   if (t->lsize > 0 && t->cur.cap > KH_L && !getenv("KH_DISABLE_XCD_GROUP")) {
     // partitions are cut for cap_u, the probes go to the (smaller) current table: 2^(PB - k) consecutive partitions share one of its chunks
     const uint32_t k_tab = log2u(t->cur.cap >> KH_LB);
@@ -1154,7 +1180,9 @@ kh_status do_insert(kh_table* t, const void* keys, uint32_t kstride, const void*
     const uint64_t cu = capacity_after(t, t->cur.cap, t->lsize, np_ ? np_ : 1, np_, np_ ? np_ - 1 : 0);
     const bool ip = inplace_ok(t, n) && t->lsize + n <= t->max_load;      // in place: no re-layout workspace, bins instead
     kh_status ps = ip ? arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + n * 48 + ws_inplace(t, n))
-                      : arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + np_ * 58 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (np_ / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
+                      // (68 B per pair: two buffers of 16-byte records in histogram-free slots of up to twice the mean fill -- a duplicate-heavy batch,
+                      //  insert_core -- + the sample set; a duplicate-free batch takes 28 B per pair of it, an exact partition 58)
+                      : arena_prepare(t, (where == KH_MEM_HOST ? n * 16 : 0) + np_ * 68 + ws_rebuild(cu) + cu * 2 + (cu > KH_L ? (cu >> KH_LB) : 1) * 64 + (np_ / KH_PART_TILE + 4096) * 16 + (size_t(1) << 20));
     if (ps != KH_OK) return ps; }
   const char* kb = static_cast<const char*>(keys);
   const char* vb = static_cast<const char*>(vals);

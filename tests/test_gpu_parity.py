@@ -707,26 +707,32 @@ def test_tiny_and_odd_initial_capacities(oracle, kname, cls, kind, cap0):
 def test_counting_insert_with_key_only_records(kname, cls, kind, monkeypatch):
     """Reducer = std::plus with the implicit value 1 on a batch the sample finds heavy in duplicates (the k-mer counter's batches):
     the partition records are the keys alone (8 bytes).  Counts equal numpy's, and the table is bit-identical to the one the
-    16-byte-record path builds (KH_DISABLE_REC8), for a batch into an empty table and a second one into the populated table."""
+    16-byte-record path builds (KH_DISABLE_REC8) and to the one behind exact partition offsets (KH_DISABLE_DUP_SLACK), for a batch into an
+    empty table and a second one into the populated table."""
     rng = np.random.default_rng(11)
     uni = W.distinct_u64(1_200_000, seed=21)
     b1 = uni[rng.integers(0, 800_000, 5_000_000)]
     b2 = uni[rng.integers(400_000, 1_200_000, 5_000_000)]
     states = []
-    for disable in (False, True):
-        if disable:
-            monkeypatch.setenv("KH_DISABLE_REC8", "1")
+    for variant in ("", "KH_DISABLE_REC8", "KH_DISABLE_DUP_SLACK"):
+        if variant:
+            monkeypatch.setenv(variant, "1")
         g = cls(128, 0.35, 0.8)
         g.profile_enable(True)
         g.insert_reduce_plus(dev(b1))
-        assert "k_part_hist" in g.profile() and "k_dedup" in g.profile()          # sampled as duplicate-heavy: exact offsets, general path
+        # sampled as duplicate-heavy: the general path -- behind a histogram-free partition whose slots are sized for the duplicates
+        # (E[m^2] / E[m] from the sample), or behind exact offsets (histogram sweep) when that is switched off
+        assert "k_dedup" in g.profile() and ("k_part_hist" in g.profile()) == (variant == "KH_DISABLE_DUP_SLACK"), g.profile()
         g.insert_reduce_plus(dev(b2))
         sk, sv = g.sorted_items()
         uk, cnt = np.unique(np.concatenate([b1, b2]), return_counts=True)
         assert np.array_equal(sk, uk) and np.array_equal(sv, cnt.astype(np.uint32))
         states.append((g.capacity(), g.export_info().copy()))
         g.close()
-    assert states[0][0] == states[1][0] and np.array_equal(states[0][1], states[1][1])
+        if variant:
+            monkeypatch.delenv(variant)
+    for st in states[1:]:
+        assert states[0][0] == st[0] and np.array_equal(states[0][1], st[1])
 
 
 def test_shard_plan_equals_per_piece_permute():
@@ -1116,7 +1122,8 @@ def test_fused_build_look_back_time_out_falls_back_to_the_general_path():
 
 def test_histogram_free_partition_and_its_fall_backs(oracle):
     """a large batch of (nearly) distinct hashed keys is partitioned without a histogram pass (fixed slots of mean + 7
-    sigma per partition).  A sample decides: duplicate-heavy batches take exact offsets from the start; duplicates the sample misses
+    sigma per partition).  A sample decides how wide the slots are: a duplicate-heavy batch fills its partitions key by key, E[m^2] / E[m]
+    records at a time, and gets slots of mean + 7 sigma of THAT distribution (factor estimated from the sample); duplicates the sample misses
     (one key repeated 30000 times among 4e6 distinct ones) overflow a slot and the batch is redone with exact offsets."""
     n = 4_000_000                                   # capacity 2^23: 4096 partitions (two partition passes) of ~977 records
     keys = W.distinct_u64(n, seed=123); vals = np.arange(n, dtype=np.uint32)
@@ -1141,8 +1148,8 @@ def test_histogram_free_partition_and_its_fall_backs(oracle):
             # no-fold build on 12-byte records (no stream positions) notices, the batch is partitioned again with 16-byte records and exact
             # offsets, and the one-launch build WITH the fold takes it (300 duplicates do not change the capacity)
             assert "k_part_hist" in p and p["k_part_scatter"][0] == 4 and p["k_build_fused"][0] == 2 and "k_dedup" not in p, p
-        elif variant == "duplicate_heavy":
-            assert "k_part_hist" in p and p["k_part_scatter"][0] == 2, p
+        elif variant == "duplicate_heavy":          # histogram-free as well, with slots sized for the duplicates (variance factor from the sample)
+            assert "k_part_hist" not in p and p["k_part_scatter"][0] == 2 and "k_dedup" in p, p
         else:
             assert "k_part_hist" in p and p["k_part_scatter"][0] == 4, p       # histogram-free attempt, then exact
         check_state(g, o, 0)
