@@ -1308,6 +1308,21 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
     const uint32_t G = P.xcd_group, x = q & 7u, row = q >> 3;
     q = (((row / G) << 3) + x) * G + (row & (G - 1u));
   }
+  // one source in fixed slots (histogram-free partition): the slot lies where it lies whatever its fill, so the first tile's records are
+  // requested together with the slot's cursor (indices clamped to the slot; the fill masks them below) -- one HBM round trip in front of the
+  // first fold instead of two
+  ulonglong2 pre[KH_DD_M / KH_CHUNK_THREADS];
+  const bool have_pre = P.src.n == 1 && P.src.slot[0] != 0 && (REC8 ? P.src.rec12 == 2 : P.src.rec12 == 0);
+  if (have_pre) {
+    const uint64_t b0 = (uint64_t)q * P.src.slot[0];
+    const uint32_t lastc = (uint32_t)P.src.slot[0] - 1u;
+#pragma unroll
+    for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) {
+      const uint32_t i = it * KH_CHUNK_THREADS + tid;
+      if (REC8) pre[it] = make_ulonglong2(reinterpret_cast<const uint64_t*>(P.src.rec[0])[b0 + (i < lastc ? i : lastc)], 1ull);
+      else pre[it] = P.src.rec[0][b0 + (i < lastc ? i : lastc)];
+    }
+  }
   const KhSrcView V = REC8 ? kh_src_setup8(P.src, q) : kh_src_setup(P.src, q, s_ptr, s_cum);
   const uint32_t m = V.m;
   const uint64_t beg = P.src.merged_off[q];            // output list of this partition
@@ -1346,7 +1361,10 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_dedup(KhDedupParams P) {
           if (take_n) {                                    // (an empty partition has nothing to read: m - 1 would wrap)
             ulonglong2 rr[KH_DD_M / KH_CHUNK_THREADS];
             const uint32_t last = m - 1u;
-            if (REC8) {       // counting insert: 8-byte keys, every value 1
+            if (have_pre && pos == 0) {       // (requested at the top, with the cursor)
+#pragma unroll
+              for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) rr[it] = pre[it];
+            } else if (REC8) {       // counting insert: 8-byte keys, every value 1
 #pragma unroll
               for (uint32_t it = 0; it < KH_DD_M / KH_CHUNK_THREADS; ++it) { const uint32_t i = pos + it * KH_CHUNK_THREADS + tid; rr[it] = make_ulonglong2(V.one8[i < last ? i : last], 1ull); }
             } else if (V.one) {

@@ -23,10 +23,10 @@ def test_no_scratch_no_spills(resources):
         assert r.get("Scratch", 0) == 0 and r.get("VGPRSpill", 0) == 0, (name, r)
         # scalar registers spilled into vector lanes cost a v_writelane each, no memory traffic: tolerated only in the one-lane
         # clean-up kernels (k_ip_serial, k_small_batch), in the key-transform (bimolecule) variants of k_find (..Lb1E..) and in the
-        # general path's k_dedup (a handful of scalars parked in lanes once per workgroup: it sits at the 106-SGPR limit of a 512-lane
-        # workgroup since the deferred reducer-plus list joined it), never on the kernels the configs[1] benchmark runs
+        # general path's k_dedup (up to 20 scalars parked in lanes once per workgroup: it sits at the 106-SGPR limit of a 512-lane
+        # workgroup since the deferred reducer-plus list and the early request of the first tile joined it), never on the kernels the configs[1] benchmark runs
         if "k_dedup" in name:
-            assert r.get("SGPRSpill", 0) <= 12, (name, r)
+            assert r.get("SGPRSpill", 0) <= 20, (name, r)
         elif "k_build_lean" in name:
             # the lean bulk build is compiled for 8 waves per SIMD (4 workgroups per CU): the 800 scalar registers of a SIMD then leave 96
             # per wave and ~30 of its ~105 scalars live in vector lanes instead (v_writelane / v_readlane, no memory): measured 6 % faster
