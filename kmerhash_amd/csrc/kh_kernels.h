@@ -12,7 +12,8 @@
 //     folded together in LDS (SRC 2: insert into a non-empty table) or from the table minus the chunk's erase keys (SRC 3: batch
 //     erase).  The benchmark case of SRC 0 (distinct keys, one source of 12-byte records) has its own kernel, k_build_lean (four
 //     workgroups per CU; sort without the carry-in, look-back collected late), and so has the batch erase: k_erase_stream scans the
-//     chunk's slots IN SLOT ORDER (a Robin Hood table is sorted by home bucket already) -- no staging, counting or ranking.
+//     chunk's slots IN SLOT ORDER (a Robin Hood table is sorted by home bucket already) -- no staging, counting or ranking; and the insert
+//     into a loaded table whose capacity stays: k_insert_stream (the table's elements in slot order, the batch's records chained per bucket).
 //     The general path is k_dedup -> k_chunk_count -> k_chunk_carry -> k_chunk_place.
 //   * Batches of <= 16 keys are applied in place by one lane (k_small_batch), mid-size batches in place by one lane per region of
 //     512 slots (k_ip_bin / k_ip_apply / k_ip_serial).
@@ -1108,6 +1109,10 @@ __device__ __forceinline__ uint32_t kh_wave_append(bool want, uint32_t* counter)
   }
   return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
+__device__ __forceinline__ uint32_t kh_wave_sum(uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 __device__ __forceinline__ uint32_t kh_wave_max(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
   return v;
@@ -1938,7 +1943,10 @@ __device__ __forceinline__ uint32_t kh_stage_from_table(const KhRebuildParams& R
 
 #ifdef KH_TRACE
 __device__ unsigned long long kh_trace[512 * 12];
-#define KH_STAMP(i) do { if (SRC == 0 && threadIdx.x == 0 && blockIdx.x >= 20000 && blockIdx.x < 20512) kh_trace[(blockIdx.x - 20000) * 12 + (i)] = clock64(); } while (0)
+#ifndef KH_TRACE_SRC
+#define KH_TRACE_SRC 0          // which source mode of k_build_fused the stamps follow
+#endif
+#define KH_STAMP(i) do { if (SRC == KH_TRACE_SRC && threadIdx.x == 0 && blockIdx.x >= 20000 && blockIdx.x < 20512) kh_trace[(blockIdx.x - 20000) * 12 + (i)] = clock64(); } while (0)
 #else
 #define KH_STAMP(i)
 #endif
@@ -2041,6 +2049,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
       return;
     }
     const uint32_t n_old = kh_stage_from_table<KIND, HASH, true>(P.R, c, Sc, lk, liv, &s_x, &s_max);     // (ends with a barrier)
+    KH_STAMP(1);
     m = n_old + V.m;
     vote_old = n_old; vote_rec = V.m;
     if (n_old >= KH_DD_M || m >= KH_DD_M) {
@@ -2074,6 +2083,7 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS) void k_build_fused(KhFusedParams 
     __syncthreads();
     rep_mask = kh_dd_fold(lk, liv, set, m, P.mode, P.seed.xk);
     __syncthreads();
+    KH_STAMP(2);
   } else if (SRC == 3) {
     // ---- batch erase without random access into HBM: the chunk's elements (home from the info byte: no hash) are staged next to the
     // batch's erase keys of this chunk (8-byte records, partitioned by chunk like an insert batch); an element whose key is among
@@ -2896,6 +2906,339 @@ __global__ __launch_bounds__(KH_CHUNK_THREADS, 8) void k_erase_stream(KhFusedPar
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Insert into a loaded Robin Hood table at EQUAL capacity as an ordered stream (what k_build_fused<.., 2> does, for batches of up to
+// KH_IS_MAXR records per chunk): the chunk's elements stay in registers in slot order (rows of 64 slots per wave, as k_erase_stream) and
+// never pass through a staging area or the de-dup set; the batch's records of the chunk (a few hundred) are chained per home bucket in LDS,
+// settle their own duplicates by walking their chain (smallest stream position wins; Reducer = std::plus: the winner takes the sum), and
+// every element of the table looks its bucket's chain up -- a record whose key the table holds is dropped (or added to the element).  Home
+// counts (elements first: their rank inside a bucket is what the counter returns; then the surviving records), a (max,+) scan over the
+// buckets, and every entry enters the image of the new chunk at max(start0[b] + rank, carry + npre[b] + rank); rows stored coalesced.
+// One HBM round trip in front (cursor, records and slots together) instead of three.  Same protocol and fall-backs as k_build_fused<.., 2>
+// (granules, look-back, early give-up vote on the duplicate ratio, chunk 0 parked, flags -> general path).  52.8 KB of LDS: three workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+#define KH_IS_MAXR 640u          // records of the batch one chunk may receive
+template <int HASH>
+__global__ __launch_bounds__(KH_CHUNK_THREADS, 6) void k_insert_stream(KhFusedParams P) {
+  __shared__ unsigned long long ikey[KH_L + KH_FSPILL];      // the new chunk (+ what runs over), slot by slot
+  __shared__ uint32_t ival[KH_L + KH_FSPILL];
+  __shared__ __align__(16) uint8_t iinfo[KH_L + KH_FSPILL];  // 0 = empty slot
+  __shared__ __align__(16) uint32_t cnt16[KH_L / 2];         // two 16-bit counters per word: entries per home bucket (the value returned = rank inside the bucket)
+  __shared__ __align__(16) uint16_t start0[KH_L];            // first slot of a bucket's group without a carry-in; before the scan: chain heads (u32[1024])
+  __shared__ __align__(8) uint16_t npre[KH_L];               // entries in the buckets before
+  __shared__ unsigned long long rk[KH_IS_MAXR];              // the batch's records of this chunk: key, stream position + 1 << 32 | value
+  __shared__ unsigned long long riv[KH_IS_MAXR];
+  __shared__ uint16_t rnx[KH_IS_MAXR];                       // chain link
+  __shared__ uint8_t rst[KH_IS_MAXR];                        // 0: survives; bit 0: a record with the same key came earlier; bit 1: the table holds the key
+  __shared__ KhMP32 s_wtot[KH_CHUNK_THREADS / 64];
+  __shared__ uint32_t s_x, s_abort, s_new, s_max;
+  uint32_t* heads = reinterpret_cast<uint32_t*>(start0);
+  constexpr uint32_t NW = KH_CHUNK_THREADS / 64, ROWS = 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint64_t cap = P.New.cap, mask_n = cap - 1;          // (same capacity as the source)
+  const uint32_t nch = (uint32_t)(cap >> KH_LB);
+  const uint32_t c = blockIdx.x;
+  const uint64_t Sc = (uint64_t)c * KH_L;
+  const unsigned long long VALID = 1ull << 63;
+  const uint32_t q = P.PB ? (__brev(c) >> (32 - P.PB)) : 0u;
+  const KhSlot* __restrict__ old = P.R.Old.s;
+  const uint32_t xk = P.seed.xk;
+  const bool plus = P.mode == KH_DEDUP_PLUS;
+  if (tid == 0) { s_abort = (uint32_t)__hip_atomic_load(&P.est[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_new = 0; s_max = 0; }
+  // ---- everything the chunk reads, requested at once (fixed slots; exact offsets cost a dependent load in front of the records)
+  const uint32_t base = wid * 256u + lane;
+  const uint32_t nrows = wid == NW - 1 ? ROWS : 4u;
+  const bool fixed = P.src.slot[0] != 0;
+  uint4 w[ROWS];
+  if (!fixed) {
+#pragma unroll
+    for (uint32_t k = 0; k < ROWS; ++k) if (k < nrows) w[k] = kh_slot_ld(old + ((Sc + base + 64u * k) & mask_n));
+  }
+  const uint64_t kb = fixed ? (uint64_t)q * P.src.slot[0] : P.src.off[0][q];
+  const uint64_t kcount = fixed ? P.src.slot[0] : P.src.off[0][q + 1] - kb;
+  const ulonglong2* srcr = kcount ? P.src.rec[0] + kb : reinterpret_cast<const ulonglong2*>(old);
+  const uint32_t rlast = kcount ? (uint32_t)(kcount < KH_IS_MAXR ? kcount : KH_IS_MAXR) - 1u : 0u;
+  ulonglong2 myrec[2];
+#pragma unroll
+  for (uint32_t u = 0; u < 2; ++u) { const uint32_t i = tid + u * KH_CHUNK_THREADS; myrec[u] = srcr[i < rlast ? i : rlast]; }
+  static_assert(KH_IS_MAXR <= 2 * KH_CHUNK_THREADS, "two records per lane");
+  if (fixed) {
+#pragma unroll
+    for (uint32_t k = 0; k < ROWS; ++k) if (k < nrows) w[k] = kh_slot_ld(old + ((Sc + base + 64u * k) & mask_n));
+  }
+  uint64_t fill = kcount;
+  if (fixed) { fill = P.src.cur[0][q] - kb; if (fill > kcount) fill = kcount; }
+  const uint32_t m_r = fill > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)fill;
+  kh_lds_fill16(cnt16, sizeof(cnt16), 0u);
+  kh_lds_fill16(start0, sizeof(start0), 0u);          // (the chain heads)
+  kh_lds_fill16(iinfo, sizeof(iinfo), 0u);
+  static_assert((KH_L + KH_FSPILL) % 16 == 0, "filled with 16-byte stores");
+  __syncthreads();
+  if (m_r > KH_IS_MAXR || s_abort != 0) {
+    if (tid == 0) {
+      if (s_abort == 0) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+      __hip_atomic_store(&P.pub[c], VALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // ---- the records: into LDS, chained per home bucket (buckets b and b + 1024 share a chain: the walks compare keys)
+  uint32_t hbr[2];
+#pragma unroll
+  for (uint32_t u = 0; u < 2; ++u) {
+    const uint32_t i = tid + u * KH_CHUNK_THREADS;
+    hbr[u] = 0;
+    if (i < m_r) {
+      rk[i] = myrec[u].x; riv[i] = myrec[u].y + (1ull << 32);       // position + 1: 0 is "already in the table"
+      rst[i] = 0;
+      hbr[u] = (uint32_t)((kh_hash64<HASH>(myrec[u].x, P.seed) & mask_n) - Sc) & (KH_L - 1u);
+      rnx[i] = (uint16_t)atomicExch(&heads[hbr[u] & 1023u], i + 1u);
+    }
+  }
+  __syncthreads();
+  // ---- duplicates inside the batch: the record with the smallest stream position stands for its key (and, Reducer = std::plus, takes the sum)
+  uint32_t rsum[2];
+#pragma unroll
+  for (uint32_t u = 0; u < 2; ++u) {
+    const uint32_t i = tid + u * KH_CHUNK_THREADS;
+    rsum[u] = 0;
+    if (i < m_r) {
+      const unsigned long long key = myrec[u].x, mine = myrec[u].y + (1ull << 32);
+      uint32_t sum = (uint32_t)mine;
+      bool later = false;
+      uint32_t e = heads[hbr[u] & 1023u];
+      while (e) {
+        const uint32_t j = e - 1u;
+        if (j != i && kh_keq(rk[j], key, xk)) {
+          const unsigned long long other = riv[j];
+          if ((other >> 32) < (mine >> 32)) later = true;
+          sum += (uint32_t)other;
+        }
+        e = rnx[j];
+      }
+      if (later) rst[i] = 1;
+      rsum[u] = sum;
+    }
+  }
+  __syncthreads();
+  if (plus) {       // (uniform) the winners carry the sums from here on
+#pragma unroll
+    for (uint32_t u = 0; u < 2; ++u) {
+      const uint32_t i = tid + u * KH_CHUNK_THREADS;
+      if (i < m_r && rst[i] == 0) riv[i] = (riv[i] & 0xFFFFFFFF00000000ull) | rsum[u];
+    }
+    __syncthreads();
+  }
+  // ---- the table's elements, in slot order: each looks its bucket's chain up (a record of the same key is dropped, or added), then counts
+  uint32_t keep = 0;
+  uint32_t rank[ROWS];               // home bucket << 16 | rank inside it
+#pragma unroll
+  for (uint32_t k = 0; k < ROWS; ++k) {
+    rank[k] = 0;
+    if (k < nrows) {
+      const int srel = (int)(base + 64u * k);
+      const uint32_t inf = w[k].w & 0xFFu;
+      const int home = srel - (int)(inf & 0x7Fu);
+      if (inf >= 0x80u && home >= 0 && home < (int)KH_L) {
+        keep |= 1u << k;
+        const unsigned long long key = kh_slot_key(w[k]);
+        uint32_t e = heads[(uint32_t)home & 1023u];
+        while (e) {
+          const uint32_t j = e - 1u;
+          if (kh_keq(rk[j], key, xk)) {
+            if (plus && rst[j] == 0) w[k].z += (uint32_t)riv[j];      // (one element per key, one winner per key: no race)
+            rst[j] |= 2;      // (byte writes of different lanes to one record: the same bit)
+          }
+          e = rnx[j];
+        }
+        const uint32_t r = (atomicAdd(&cnt16[(uint32_t)home >> 1], 1u << (16 * (home & 1))) >> (16 * (home & 1))) & 0xFFFFu;
+        rank[k] = ((uint32_t)home << 16) | r;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the surviving records count behind the elements of their bucket
+  uint32_t rrank[2];
+  uint32_t my_max = 0, my_new = 0;
+#pragma unroll
+  for (uint32_t u = 0; u < 2; ++u) {
+    const uint32_t i = tid + u * KH_CHUNK_THREADS;
+    rrank[u] = 0xFFFFFFFFu;
+    if (i < m_r && rst[i] == 0) {
+      const uint32_t b = hbr[u];
+      rrank[u] = (atomicAdd(&cnt16[b >> 1], 1u << (16 * (b & 1))) >> (16 * (b & 1))) & 0xFFFFu;
+      ++my_new;
+      const uint32_t ix = (uint32_t)(riv[i] >> 32);                  // stream position + 1 of a NEW key's first occurrence
+      my_max = ix > my_max ? ix : my_max;
+    }
+  }
+  my_new = kh_wave_sum(my_new);
+  my_max = kh_wave_max(my_max);
+  if (lane == 0) { if (my_new) atomicAdd(&s_new, my_new); if (my_max && P.mode == KH_DEDUP_FIRST) atomicMax(&s_max, my_max); }
+  __syncthreads();
+  // ---- (max,+) scan over the home buckets: group starts without the carry-in, entries in front of every bucket
+  uint32_t cb[KH_HOMES_PER_THREAD];
+  KhMP32 v; v.A = KH_MP32_NEG; v.n = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+    const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+    cb[j] = (cnt16[b >> 1] >> (16 * (b & 1))) & 0xFFFFu;
+    KhMP32 h; h.A = (int)(b + cb[j]); h.n = (int)cb[j];
+    v = kh_mp_combine(v, h);
+  }
+  KhMP32 total;
+  const KhMP32 excl = kh_block_scan_mp32(v, s_wtot, &total);
+  const uint32_t n_c = (uint32_t)total.n;
+  const uint32_t n_new = s_new, n_old = n_c - n_new;
+  const long long spill0 = total.A > (int)KH_L ? (long long)total.A - (long long)KH_L : 0;
+  const bool early = n_c + KH_XB <= KH_L;
+  {
+    long long p = excl.A > (long long)excl.n ? excl.A : excl.n;
+    uint32_t np = (uint32_t)excl.n;
+    uint32_t st4[KH_HOMES_PER_THREAD], np4[KH_HOMES_PER_THREAD];
+#pragma unroll
+    for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) {
+      const uint32_t b = tid * KH_HOMES_PER_THREAD + j;
+      const long long st = p > (long long)b ? p : (long long)b;
+      st4[j] = (uint32_t)st & 0xFFFFu;
+      np4[j] = np;
+      p = st + cb[j];
+      np += cb[j];
+    }
+    static_assert(KH_HOMES_PER_THREAD == 4, "one 8-byte store of starts / counts per thread");
+    reinterpret_cast<uint2*>(start0)[tid] = make_uint2(st4[0] | (st4[1] << 16), st4[2] | (st4[3] << 16));      // (the chain heads are dead: every walk ended two barriers ago)
+    reinterpret_cast<uint2*>(npre)[tid] = make_uint2(np4[0] | (np4[1] << 16), np4[2] | (np4[3] << 16));
+  }
+  __syncthreads();
+  if (c == 0) {     // circular table: chunk 0 follows the last chunk -> publish, park (entries in bucket order, home counts), tail launch places
+    if (tid == 0) {
+      if (!early) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+      __hip_atomic_store(&P.pub[0], VALID | ((unsigned long long)spill0 << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      P.maxidx[0] = s_max;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < KH_HOMES_PER_THREAD; ++j) P.homecnt0[tid * KH_HOMES_PER_THREAD + j] = (uint16_t)cb[j];
+#pragma unroll
+    for (uint32_t k = 0; k < ROWS; ++k) {
+      if ((keep >> k) & 1u) {
+        const uint32_t idx = npre[rank[k] >> 16] + (rank[k] & 0xFFFFu);
+        if (idx < KH_DD_M) { P.ck0[idx] = kh_slot_key(w[k]); P.cv0[idx] = w[k].z; }
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 2; ++u) {
+      if (rrank[u] != 0xFFFFFFFFu) {
+        const uint32_t i = tid + u * KH_CHUNK_THREADS;
+        const uint32_t idx = npre[hbr[u]] + rrank[u];
+        if (idx < KH_DD_M) { P.ck0[idx] = rk[i]; P.cv0[idx] = (uint32_t)riv[i]; }
+      }
+    }
+    return;
+  }
+  // ---- publish, vote, request the word of the chunk before
+  unsigned long long w0 = 0;
+  if (tid == 0) {
+    if (c < 64) {     // the first 64 chunks vote on the duplicate ratio (as k_build_fused<.., 2>)
+      const unsigned long long mine = ((unsigned long long)n_new << 32) | m_r;     // new distinct keys, records
+      const unsigned long long tot = atomicAdd(&P.est[0], mine) + mine;
+      const uint32_t sn = (uint32_t)(tot >> 32), sm = (uint32_t)tot;
+      if ((c == 63 || (nch < 64 && c == nch - 1)) && sm > 0) {
+        const double dhat = (double)P.base_size + (double)P.n_total * (double)sn / (double)sm * 1.15;
+        if (dhat <= (double)P.half_max_load) {
+          atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+          __hip_atomic_store(&P.est[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (early) __hip_atomic_store(&P.pub[c], VALID | ((unsigned long long)spill0 << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w0 = __hip_atomic_load(&P.pub[c - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    P.maxidx[c] = s_max;
+  }
+  // ---- every entry into the image: slot = max(start0[b] + rank, carry + npre[b] + rank); what cannot depend on the carry-in (<= KH_XB) at once
+  auto enter = [&](unsigned long long key, uint32_t val, uint32_t b, uint32_t pos) {
+    uint32_t dist = pos - b;
+    if (dist > 127u) { atomicOr(&P.flags[KH_FLAG_PROBE_OVERFLOW], 1u); dist = 127u; }
+    if (pos < KH_L + KH_FSPILL) { ikey[pos] = key; ival[pos] = val; iinfo[pos] = (uint8_t)(0x80u | dist); }
+    else kh_slot_st(P.New.s + ((Sc + pos) & mask_n), key, val, 0x80u | dist);
+  };
+  uint32_t late = 0;
+  uint32_t pj[ROWS + 2];             // slot without carry-in | sorted index << 16
+#pragma unroll
+  for (uint32_t k = 0; k < ROWS; ++k) {
+    pj[k] = 0;
+    if ((keep >> k) & 1u) {
+      const uint32_t b = rank[k] >> 16, r = rank[k] & 0xFFFFu;
+      const uint32_t p0 = start0[b] + r, j = npre[b] + r;
+      pj[k] = (p0 & 0xFFFFu) | (j << 16);
+      if (p0 >= KH_XB + j) enter(kh_slot_key(w[k]), w[k].z, b, p0); else late |= 1u << k;
+    }
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < 2; ++u) {
+    pj[ROWS + u] = 0;
+    if (rrank[u] != 0xFFFFFFFFu) {
+      const uint32_t i = tid + u * KH_CHUNK_THREADS;
+      const uint32_t b = hbr[u], r = rrank[u];
+      const uint32_t p0 = start0[b] + r, j = npre[b] + r;
+      pj[ROWS + u] = (p0 & 0xFFFFu) | (j << 16);
+      if (p0 >= KH_XB + j) enter(rk[i], (uint32_t)riv[i], b, p0); else late |= 1u << (ROWS + u);
+    }
+  }
+  if (tid == 0) {
+    unsigned long long ww = w0;
+    const long long t0 = clock64();
+    while (!(ww & VALID)) {
+      if (clock64() - t0 > P.poll_limit) { atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u); ww = VALID; break; }   // bounded: then the general path
+      __builtin_amdgcn_s_sleep(4);
+      ww = __hip_atomic_load(&P.pub[c - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t x = (uint32_t)((ww >> 32) & 0x7FFFFFFFu);
+    if (x > KH_XB) atomicOr(&P.flags[KH_FLAG_FUSE_INVALID], 1u);
+    if (!early) {
+      const long long e = (long long)x + n_c;
+      const long long pe = (long long)total.A > e ? (long long)total.A : e;
+      const long long sp = pe > (long long)KH_L ? pe - (long long)KH_L : 0;
+      __hip_atomic_store(&P.pub[c], VALID | ((unsigned long long)sp << 32) | n_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_x = x > KH_XB ? 0u : x;
+  }
+  __syncthreads();
+  const uint32_t xr = s_x;
+#pragma unroll
+  for (uint32_t k = 0; k < ROWS; ++k) {
+    if ((late >> k) & 1u) {
+      const uint32_t p0 = pj[k] & 0xFFFFu, pc = (pj[k] >> 16) + xr;
+      enter(kh_slot_key(w[k]), w[k].z, rank[k] >> 16, p0 > pc ? p0 : pc);
+    }
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < 2; ++u) {
+    if ((late >> (ROWS + u)) & 1u) {
+      const uint32_t i = tid + u * KH_CHUNK_THREADS;
+      const uint32_t p0 = pj[ROWS + u] & 0xFFFFu, pc = (pj[ROWS + u] >> 16) + xr;
+      enter(rk[i], (uint32_t)riv[i], hbr[u], p0 > pc ? p0 : pc);
+    }
+  }
+  __syncthreads();
+  // ---- the new chunk, row by row: every slot of [carry-in, end of the layout) is stored once, 1 KB per wave and store
+  {
+    const int tA = total.A > 0 ? total.A : 0;
+    int pend = tA > (int)xr + (int)n_c ? tA : (int)xr + (int)n_c;
+    if (pend < (int)KH_L) pend = (int)KH_L;
+    if (pend > (int)(KH_L + KH_FSPILL)) pend = (int)(KH_L + KH_FSPILL);
+#pragma unroll
+    for (uint32_t k = 0; k < ROWS; ++k) {
+      const int s0 = (int)(base + 64u * k);
+      if (k < nrows && s0 >= (int)xr && s0 < pend) {
+        const uint32_t ib = iinfo[s0];
+        KhSlot* dst = P.New.s + ((Sc + (uint32_t)s0) & mask_n);
+        if (ib == 0u) kh_slot_st(dst, 0, 0, kh_empty_info<KHK_RH>());
+        else kh_slot_st(dst, ikey[s0], ival[s0], ib);
+      }
+    }
+  }
+  (void)n_old;
 }
 
 // carry-in of chunk 0 = run-over of the last chunk (circular table)

@@ -364,6 +364,7 @@ kh_status launch_fused(kh_table* t, int src, KhFusedParams& F, const KhSlots& nw
     else if (src == 1) { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 1>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }
     else if (src == 3) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_build_fused<KHK_RH, HASH, 3>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }      // (batch erase: Robin Hood only)
     else if (src == 4) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_erase_stream<HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }              // (batch erase as an ordered stream)
+    else if (src == 5) { KH_SWITCH_HASH(t->hash, hipLaunchKernelGGL((k_insert_stream<HASH>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); }             // (insert into a loaded table as an ordered stream)
     else { KH_SWITCH_KIND_HASH(t->kind, t->hash, hipLaunchKernelGGL((k_build_fused<KIND, HASH, 2>), dim3(nch), dim3(KH_CHUNK_THREADS), 0, t->stream, F)); } }
   { Launch L(t, "k_fused_totals");
     hipLaunchKernelGGL(k_fused_totals, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(64u, nch / 1024u))), dim3(1024), 0, t->stream, F.pub, maxidx, nch, totals); }
@@ -857,7 +858,10 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
     F.half_max_load = (cap_u >> 1) >= t->cur.cap ? threshold(cap_u >> 1, t->max_lf) : 0;
     F.R.Old = t->cur; F.R.PB = PB;
     FusedRun run;
-    { kh_status fs = launch_fused(t, 2, F, nw, PB, "k_insert_fused", &run); if (fs != KH_OK) return fs; }
+    // (Robin Hood at equal capacity, one source of 16-byte records, a chunk's records fit two per lane: the ordered-stream kernel; else the staging form)
+    const bool ordered = t->kind == KHK_RH && cap_u == t->cur.cap && S.n == 1 && S.rec12 == 0 &&
+                         (S.slot[0] ? S.slot[0] <= KH_IS_MAXR : n / (uint64_t(1) << PB) <= KH_IS_MAXR / 2) && !getenv("KH_DISABLE_ORDERED_INSERT");
+    { kh_status fs = launch_fused(t, ordered ? 5 : 2, F, nw, PB, "k_insert_fused", &run); if (fs != KH_OK) return fs; }
     if (t->part_overflow && (uint32_t)t->hpin[30]) { retire_slots(t, nw); return KH_RETRY_EXACT; }
     const uint64_t total = t->hpin[0];
     const uint64_t fd = total >= t->lsize ? total - t->lsize : 0;

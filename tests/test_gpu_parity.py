@@ -1354,6 +1354,67 @@ def test_duplicate_heavy_batches_into_a_loaded_table(oracle, hname, hid):
     g.close()
 
 
+@pytest.mark.parametrize("n0,nb,cap", [(3_000_000, 250_000, 1 << 22), (5_000_000, 1_000_000, 1 << 23)])
+def test_insert_into_a_loaded_table_as_an_ordered_stream(oracle, monkeypatch, n0, nb, cap):
+    """k_insert_stream: a batch into a loaded Robin Hood table whose capacity stays (the table's elements in slot order, the batch's records
+    chained per home bucket).  New keys, keys the table holds, keys given several times inside the batch; exact partition offsets (2^22
+    buckets) and fixed slots (2^23); first-wins insert against the oracle, reducer-plus (with values, then counting) against a numpy model,
+    a bimolecule table fed the other strand; the staging form (test hook) leaves the same table."""
+    base = W.distinct_u64(n0, seed=91); bv = np.arange(n0, dtype=np.uint32)
+    fresh = W.distinct_u64(nb * 6 // 10, seed=92)
+    batch = np.concatenate([fresh, base[: nb * 24 // 100], fresh[: nb * 16 // 100]])[W.shuffle_perm(nb, 7)]      # 60 % new, 24 % held, 16 % repeats
+    vals = (np.arange(nb, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(2**32)).astype(np.uint32)
+    infos = []
+    for ordered in (True, False):
+        if not ordered:
+            monkeypatch.setenv("KH_DISABLE_ORDERED_INSERT", "1")
+        g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8); o = oracle.OracleTable(0, 128, 0.35, 0.8)
+        assert g.insert(dev(base), dev(bv)) == o.insert(base, bv) and g.capacity() == cap
+        g.profile_enable(True)
+        assert g.insert(dev(batch), dev(vals)) == o.insert(batch, vals) == len(fresh) and g.capacity() == cap
+        p = g.profile()
+        assert "k_insert_fused" in p and "k_dedup" not in p, p
+        check_state(g, o, 0)
+        check_queries(g, o, np.concatenate([fresh[:3000], base[:3000], W.distinct_u64(3000, seed=93)]))
+        infos.append(g.export_info().copy())
+        g.close()
+    monkeypatch.delenv("KH_DISABLE_ORDERED_INSERT")
+    assert np.array_equal(infos[0], infos[1])
+    # Reducer = std::plus: with values, then the same batch again (every key held now)
+    g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8)
+    g.insert(dev(base), dev(bv))
+    g.profile_enable(True)
+    assert g.insert_reduce_plus(dev(batch), dev(vals)) == len(fresh)
+    assert g.insert_reduce_plus(dev(batch), dev(vals)) == 0
+    assert "k_insert_fused" in g.profile(), g.profile()
+    uk, inv = np.unique(batch, return_inverse=True)
+    add = np.zeros(len(uk), dtype=np.uint64); np.add.at(add, inv, vals.astype(np.uint64))
+    exp = dict(zip(base.tolist(), bv.tolist()))
+    for k, a in zip(uk.tolist(), add.tolist()):
+        exp[k] = (exp.get(k, 0) + 2 * a) & 0xFFFFFFFF
+    sk, sv = g.sorted_items()
+    ek = np.array(sorted(exp), dtype=np.uint64)
+    assert np.array_equal(sk, ek) and np.array_equal(sv, np.array([exp[int(k)] for k in ek], dtype=np.uint32))
+    assert g.capacity() == cap and np.array_equal(g.export_info(), infos[0])
+    g.close()
+    if cap == 1 << 22:      # bimolecule table: the batch brings the other strand of keys the table holds, and both strands of new ones
+        k = 31
+        kk = W.distinct_u64(n0 + 200_000, seed=94) & np.uint64((1 << (2 * k)) - 1)
+        kk = kk[np.unique(np.minimum(kk, _revcomp(kk, k)), return_index=True)[1]]
+        kb, kn = kk[:n0 - 100_000], kk[n0 - 100_000:][:150_000]
+        g = kh.hashmap_robinhood_doubling(128, 0.35, 0.8, hash="farm"); g.set_key_transform(k)
+        o = oracle.OracleTable(0, 128, 0.35, 0.8, 3, 43); o.set_key_transform(k)
+        vb = np.arange(len(kb), dtype=np.uint32)
+        assert g.insert(dev(kb), dev(vb)) == o.insert(kb, vb)
+        b2 = np.concatenate([kn, _revcomp(kn[:50_000], k), _revcomp(kb[:60_000], k)])[W.shuffle_perm(len(kn) + 110_000, 9)]
+        v2 = np.arange(len(b2), dtype=np.uint32) + np.uint32(7_000_000)
+        g.profile_enable(True)
+        assert g.insert(dev(b2), dev(v2)) == o.insert(b2, v2) == len(kn)
+        assert "k_insert_fused" in g.profile() and "k_dedup" not in g.profile(), g.profile()
+        check_state(g, o, 0)
+        g.close()
+
+
 def test_bulk_build_of_a_table_filled_to_0_9(oracle):
     """max load factor 0.9, filled to the threshold exactly (7 549 747 keys -> 2^23 buckets, 1843 records per chunk on average): the lean bulk
     build's staging arrays (2016 records) would be too small for a chunk or two of 4096, so the build goes to k_build_fused -- ONE launch, no

@@ -39,7 +39,7 @@ def test_no_scratch_no_spills(resources):
             assert r.get("SGPRSpill", 0) == 0, (name, r)
 
 
-@pytest.mark.parametrize("kernel,min_occ", [("k_build_fused", 6), ("k_build_lean", 8), ("k_erase_stream", 8), ("k_dedup", 6), ("k_chunk_place", 6), ("k_part_scatter", 4)])
+@pytest.mark.parametrize("kernel,min_occ", [("k_build_fused", 6), ("k_build_lean", 8), ("k_erase_stream", 8), ("k_insert_stream", 6), ("k_dedup", 6), ("k_chunk_place", 6), ("k_part_scatter", 4)])
 def test_lds_bound_kernels_keep_their_occupancy(resources, kernel, min_occ):
     hits = {n: r for n, r in resources.items() if kernel + "I" in n}
     assert hits, kernel
