@@ -143,6 +143,7 @@ struct kh_table {
     uint64_t* stage_k; uint32_t* stage_v;
   } ins;
   uint32_t* part_overflow;      // device flag of the histogram-free partition feeding the operation in flight (or null)
+  double batch_vf;              // variance factor E[m^2]/E[m] the duplicate sample gave for the batch in flight (1: no duplicate seen)
   bool batch_nodup;             // a sample of the batch in flight found no duplicate key (k_sample_dups)
   bool prof;
   std::vector<ProfRec> recs;
@@ -766,9 +767,9 @@ kh_status insert_core(kh_table* t, const char* kbase, uint32_t kstride, const ch
     memset(&S, 0, sizeof(S));
     S.rec[0] = R.rec; S.off[0] = R.part_off; S.n = 1; S.merged_off = R.part_off; S.slot[0] = R.slot; S.cur[0] = R.cursor;
     S.rec12 = (uint32_t)R.rec12;
-    t->part_overflow = R.overflow;
+    t->part_overflow = R.overflow; t->batch_vf = vf;
     st = insert_finish(t, S, n, PB, cap_u, mode, forced_cap, spare, n_new_out, m);
-    t->part_overflow = nullptr; t->batch_nodup = false;
+    t->part_overflow = nullptr; t->batch_nodup = false; t->batch_vf = 1.0;
     if (st != KH_RETRY_EXACT) return st;
   }
   return fail(t, KH_ERR_HIP, "internal: exact partition reported a slot overflow");
@@ -783,7 +784,10 @@ kh_status insert_finish(kh_table* t, KhSrcSet S, uint64_t n, uint32_t PB, uint64
   struct { uint32_t nparts; } R; R.nparts = nparts;
   // ---- fused bulk build: empty table, moderate load factor, at least two chunks.  Speculates that the capacity the
   // reference's rule yields equals cap_u (true when the batch holds few duplicates); otherwise falls through.
-  if (fused_build_applies(t, cap_u, PB) && S.rec12 != 2) {
+  // (not for a batch whose sample says that a key comes E[m^2]/E[m] >= 2 times: the build speculates that every pair is a new key, its first 64
+  //  chunks would vote it down -- 0.11 ms of launches for the reference benchmark's own input; a batch that is mostly distinct after all is
+  //  merely built by the general path)
+  if (fused_build_applies(t, cap_u, PB) && S.rec12 != 2 && !(t->batch_vf >= 2.0)) {
     const uint32_t nch = (uint32_t)(cap_u >> KH_LB);
     KhSlots nw;
     st = fresh_slots(t, cap_u, nw);
@@ -1496,7 +1500,7 @@ kh_status kh_create(kh_table** out, kh_kind kind, uint32_t key_bytes, uint32_t v
   t->kind = (int)kind; t->hash = (int)hash; t->device = device; t->seed = KhSeed{seed, 0u}; t->stream = nullptr;
   t->min_lf = min_lf; t->max_lf = max_lf; t->lsize = 0;
   t->cur = kNoSlots; t->spare = t->cur;
-  t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false; t->part_overflow = nullptr; t->batch_nodup = false;
+  t->blk = 0; t->off = 0; t->hpin = nullptr; t->prof = false; t->part_overflow = nullptr; t->batch_nodup = false; t->batch_vf = 1.0;
   memset(&t->ins, 0, sizeof(t->ins));
   const uint64_t cap = next_pow2(capacity);
   if (alloc_slots(t, cap, t->cur) != KH_OK) { delete t; return KH_ERR_NOMEM; }
