@@ -684,8 +684,10 @@ enum { INS_FIRST = 0, INS_UPDATE = 1, INS_PLUS = 2 };
 // Pairs one internal pass takes.  A batch is the reference's SEQUENCE of insert() calls (one doubling decision per call), so cutting it
 // into consecutive passes changes nothing observable; what it bounds is the workspace -- ~58 B per pair of a pass: a k-mer counter's
 // file batch of 1.7e9 k-mers would otherwise ask for a 100 GB arena, whose hipMalloc alone costs 0.7 s (measured, scripts/kc_scale_probe.py).
+// 2^30: a second pass is an insert into a LOADED table -- a re-layout of all of it (19 ms at 2^31 buckets) -- so 10^9 keys in one call stay one pass
+// (scripts/scale_1e9.py: 40.9 ms with passes of 2^29, against the partition + build of a single pass).
 const uint64_t g_max_pass = getenv("KH_MAX_PASS_RECORDS") ? std::max<uint64_t>(1024, std::min<uint64_t>(strtoull(getenv("KH_MAX_PASS_RECORDS"), nullptr, 10), 0xFFFFFFF0ull))
-                                                          : (uint64_t(1) << 29);
+                                                          : (uint64_t(1) << 30);
 bool g_disable_fused = getenv("KH_DISABLE_FUSED_BUILD") != nullptr;   // test hook: force the general path
 
 // second half of an insert: the n pairs have been partitioned (one source per feed); de-dup, capacity decision, build
