@@ -21,3 +21,16 @@ def test_header_compiles_as_c99_and_links(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "gfx950" in r.stdout     # status is KH_ERR_HIP (5) without a GPU, KH_OK with one
+
+
+def test_every_environment_switch_is_documented():
+    """every KH_* / KHD_* variable the libraries read (getenv in kmerhash_amd/csrc) is listed in INTEGRATION.md's table of switches"""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in ("kmerhash_amd/csrc/kmerhash_amd.hip", "kmerhash_amd/csrc/kmerhash_amd_dist.cpp", "kmerhash_amd/csrc/kh_kernels.h"):
+        names |= set(re.findall(r'getenv\("(KHD?_[A-Z0-9_]+)"\)', open(os.path.join(root, f)).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert len(names) >= 15 and not missing, missing
